@@ -1,0 +1,279 @@
+#!/usr/bin/env python
+"""tests/golden/make_golden.py — regenerates tests/golden/*.npz.
+
+Runs ONLY in the build container, where /root/reference exists: it imports the
+reference's own Python (att_speech.fst_utils, att_speech.modules.ctc_losses,
+att_speech.modules.decoders.advanced_decoder) under py3.10 with empty stub
+modules for the absent third-party packages (pywrapfst, torchtext, kaldi_io,
+tensorboardX), runs the reference functions on seeded inputs and stores
+inputs + reference outputs.  The fixtures are data only; nothing of the
+reference's source travels.
+
+Graph matrices: pywrapfst is absent, so the sparse [N,K] matrices fed to the
+reference's PathLogSumExp / path_reduction are produced by oracle/fst_oracle.py
+(our restatement of fst_utils.py:195-294,603-676); the DENSE matrices come from
+the reference's own get_CTC_matrices_mono / get_CTC_matrices_bicontext.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+
+for name in ['pywrapfst', 'torchtext', 'torchtext.vocab', 'kaldi_io',
+             'tensorboardX']:
+    sys.modules[name] = types.ModuleType(name)
+sys.modules['torchtext'].vocab = sys.modules['torchtext.vocab']
+sys.modules['torchtext.vocab'].Vocab = object
+sys.modules['tensorboardX'].SummaryWriter = object
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+from att_speech import fst_utils as ref_fst                      # noqa: E402
+from att_speech.modules import ctc_losses as ref_ctc             # noqa: E402
+from oracle import fst_oracle                                    # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def make_lp(rng, T, B, C, kind='log_softmax'):
+    x = rng.standard_normal((T, B, C)).astype(np.float32) * 2.0
+    if kind == 'log_softmax':
+        x = torch.log_softmax(t(x), -1).numpy()
+    elif kind == 'maxsub':     # what FSTDecoder feeds with normalize_by_dim=None
+        x = x - x.max(-1, keepdims=True)
+    return x
+
+
+def labels_batch(rng, B, Lmax, lo, hi, min_len=1):
+    lens = np.array([max(min_len, Lmax - 2 * b) for b in range(B)], np.int32)
+    labs = np.zeros((B, Lmax), np.int32)
+    for b in range(B):
+        labs[b, :lens[b]] = rng.integers(lo, hi + 1, size=lens[b])
+    return labs, lens
+
+
+def run_ref_lattice(lp, lens, mats):
+    """reference PathLogSumExp + autodiff logsumexp + viterbi on `mats`."""
+    tm = [t(m) for m in mats]
+    lpt = t(lp).clone().requires_grad_()
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    logz = ref_fst.path_reduction(lpt, lens_t, tm, red_kind='logsumexp',
+                                  neg_inf=-1e20)          # 8 mats -> PathLogSumExp
+    w = torch.linspace(0.5, 1.5, logz.numel())
+    (logz * w).sum().backward()
+    out = dict(fwbw_logZ=logz.detach().numpy(), fwbw_grad_w=lpt.grad.numpy(),
+               w=w.numpy())
+    # un-weighted cached grads (ctx.grads, fst_utils.py:473)
+    lpt2 = t(lp).clone().requires_grad_()
+    ref_fst.path_reduction(lpt2, lens_t, tm, red_kind='logsumexp_fwb'
+                           ).sum().backward()
+    out['fwbw_grad'] = lpt2.grad.numpy()
+    # autodiff alpha-only scan on the 4 in-edge matrices (fst_utils.py:349-397)
+    lpt3 = t(lp).clone().requires_grad_()
+    s = ref_fst.path_reduction(lpt3, lens_t, tm[:4],
+                               red_kind='logsumexp_autodiff', neg_inf=-1e20)
+    s.sum().backward()
+    out['autodiff_logZ'] = s.detach().numpy()
+    out['autodiff_grad'] = lpt3.grad.numpy()
+    # viterbi (advanced_decoder.py:546-554)
+    lpt4 = t(lp).clone().requires_grad_()
+    v = ref_fst.path_reduction(lpt4, lens_t, tm[:4], red_kind='viterbi',
+                               neg_inf=-1e20)
+    (-v.sum()).backward()
+    out['viterbi_score'] = v.detach().numpy()
+    out['viterbi_selidx'] = lpt4.grad.min(-1)[1].numpy().astype(np.int32)
+    return out
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print('wrote %s (%.1f KB)' % (name, os.path.getsize(path) / 1024.0))
+
+
+def golden_lattice_mono():
+    rng = np.random.default_rng(1001)
+    S, T, B, Lmax = 49, 40, 5, 9
+    labs, llens = labels_batch(rng, B, Lmax, 2, 48)
+    labs[0, 2] = labs[0, 3]                     # force a repeated label
+    lens = np.array([40, 37, 33, 30, 22], np.int32)
+    lp = make_lp(rng, T, B, S)
+    gg = fst_oracle.CTCGraphGen(S, 1)
+    mats = gg.get_training_matrices_batch(labs, llens)
+    out = run_ref_lattice(lp, lens, mats)
+    # reference dense path on the same problem (ctc_losses.py:563-609)
+    acts = t(lp).clone().requires_grad_()
+    cat = torch.cat([t(labs[b, :llens[b]]).long() for b in range(B)])
+    dense = ref_ctc.ctc_raw_loss_batch(
+        acts, cat, torch.tensor(lens), torch.tensor(llens).long(),
+        num_symbols=S, context_order=1, normalize_by_dim=None)
+    dense.sum().backward()
+    save('lattice_mono.npz', lp=lp, lens=lens, labels=labs, label_lens=llens,
+         **{'gm%d' % i: m for i, m in enumerate(mats)},
+         dense_loss=dense.detach().numpy(), dense_grad_acts=acts.grad.numpy(),
+         **out)
+
+
+def golden_lattice_bigram():
+    """bigram numerator lattices, S=7 (C=49) and S=49 (C=2401), global blank
+    (the FST default) — sparse reference arithmetic on our graph matrices."""
+    for tag, S, T, B, Lmax, seed in [('s7', 7, 30, 4, 7, 1002),
+                                     ('s49', 49, 12, 2, 4, 1003)]:
+        rng = np.random.default_rng(seed)
+        labs, llens = labels_batch(rng, B, Lmax, 1, S - 1)
+        if tag == 's7':
+            labs[0, 1] = labs[0, 2]
+        # bigram ids prev*S+cur like WSJBigramDataset.tokenize (egs/wsj/data.py:146-161)
+        big = np.zeros_like(labs)
+        for b in range(B):
+            last = 0
+            for i in range(llens[b]):
+                big[b, i] = last * S + labs[b, i]
+                last = labs[b, i]
+        lens = np.array([T - 3 * b for b in range(B)], np.int32)
+        lp = make_lp(rng, T, B, S * S)
+        gg = fst_oracle.CTCGraphGen(S, 2)
+        mats = gg.get_training_matrices_batch(big, llens)
+        out = run_ref_lattice(lp, lens, mats)
+        save('lattice_bigram_%s.npz' % tag, lp=lp, lens=lens, labels=big,
+             label_lens=llens, S=np.int32(S),
+             **{'gm%d' % i: m for i, m in enumerate(mats)}, **out)
+
+
+def golden_dense_bicontext():
+    """reference dense bigram CTC (contextual blanks), independent of OpenFst:
+    ctc_raw_loss_batch with context_order=2 (ctc_losses.py:111-166,327-390,563-609)."""
+    rng = np.random.default_rng(1004)
+    S, T, B, Lmax = 7, 30, 4, 7
+    labs, llens = labels_batch(rng, B, Lmax, 1, S - 1)
+    labs[0, 1] = labs[0, 2]                      # adjacent repeat in utt 0
+    labs[1, :llens[1]] = (np.arange(llens[1]) % (S - 1)) + 1   # repeat-free
+    lens = np.array([T - 3 * b for b in range(B)], np.int32)
+    acts_np = rng.standard_normal((T, B, S * S)).astype(np.float32) * 2.0
+    cat = torch.cat([t(labs[b, :llens[b]]).long() for b in range(B)])
+    res = {}
+    for tag, kw in [('rep_sym', dict(eval_repeats_in_context=False)),
+                    ('rep_ctx', dict(eval_repeats_in_context=True))]:
+        acts = t(acts_np).clone().requires_grad_()
+        loss = ref_ctc.ctc_raw_loss_batch(
+            acts, cat, torch.tensor(lens), torch.tensor(llens).long(),
+            num_symbols=S, context_order=2, normalize_by_dim=1, **kw)
+        loss.sum().backward()
+        res['loss_' + tag] = loss.detach().numpy()
+        res['grad_acts_' + tag] = acts.grad.numpy()
+    lp = ref_ctc.get_normalized_acts(t(acts_np), None, S, 2, 1).numpy()
+    save('dense_bicontext.npz', acts=acts_np, log_probs=lp, lens=lens,
+         labels=labs, label_lens=llens, S=np.int32(S), **res)
+
+
+def golden_denominator():
+    """decoding (denominator) graphs shared across the batch, Bg=1:
+    mono S=49 and bigram S=7 (49 states, in-degree 9)."""
+    for tag, S, order, T, B, seed in [('mono', 49, 1, 25, 3, 1005),
+                                      ('bigram_s7', 7, 2, 25, 3, 1006)]:
+        rng = np.random.default_rng(seed)
+        C = S ** order
+        lens = np.array([T - 4 * b for b in range(B)], np.int32)
+        lp = make_lp(rng, T, B, C, kind='maxsub')
+        gg = fst_oracle.CTCGraphGen(S, order)
+        mats = gg.get_decoding_matrices()
+        out = run_ref_lattice(lp, lens, mats)
+        save('lattice_den_%s.npz' % tag, lp=lp, lens=lens, S=np.int32(S),
+             order=np.int32(order),
+             **{'gm%d' % i: m for i, m in enumerate(mats)}, **out)
+
+
+def golden_normalized_acts():
+    rng = np.random.default_rng(1007)
+    S, T, B = 7, 9, 3
+    acts = rng.standard_normal((T, B, S * S)).astype(np.float32) * 3.0
+    out = {}
+    for tag, nbd, nl in [('none_nl', None, True), ('zero', 0, True),
+                         ('one', 1, True), ('none_raw', None, False)]:
+        out[tag] = ref_ctc.get_normalized_acts(
+            t(acts), None, S, 2, nbd, normalize_logits=nl).numpy()
+    save('normalized_acts.npz', acts=acts, S=np.int32(S), **out)
+
+
+def golden_embedders_and_greedy():
+    from att_speech.modules.decoders import advanced_decoder as ad
+    from att_speech.configuration import Globals
+    Globals.cuda = False                       # configuration.py:113-115
+    torch.manual_seed(1008)
+    S, H, R = 7, 16, 11
+    # LutLinear / NGramLinear forward with saved weights (advanced_decoder.py:29-223)
+    n2c = ref_fst.make_full_ngram_table(2, S, S * S)[2]
+    x = torch.randn(R, H)
+    out = dict(x=x.numpy(), S=np.int32(S))
+    lut = ad.LutLinear(H, S, n2c)
+    lut.eval()
+    out['lut_weight'] = lut.weight.detach().numpy()
+    out['lut_bias'] = lut.bias.detach().numpy()
+    out['lut_y'] = lut(x).detach().numpy()
+    lut_t = ad.LutLinear(H, S, n2c, tie_blanks=True)
+    lut_t.eval()
+    lut_t.load_state_dict(lut.state_dict())
+    out['lut_tied_y'] = lut_t(x).detach().numpy()
+    ng = ad.NGramLinear(H, S, n2c, bias_only_for_dim=1,
+                        embedding_combination_method='concat', num_layers=3,
+                        tied_embeddings=False)
+    ng.eval()
+    with torch.no_grad():
+        ng.bias.normal_()
+    for k, v in ng.state_dict().items():
+        out['ng_' + k] = v.detach().numpy()
+    out['ng_y'] = ng(x).detach().numpy()
+    ng2 = ad.NGramLinear(H, S, n2c, embedding_combination_method='sum',
+                         num_layers=0, tied_embeddings=True)
+    ng2.eval()
+    for k, v in ng2.state_dict().items():
+        out['ng2_' + k] = v.detach().numpy()
+    out['ng2_y'] = ng2(x).detach().numpy()
+
+    # CTCDecoderAdvanced.process_sequence, bug-compatible default branch
+    # (advanced_decoder.py:378-391), called unbound on a minimal stand-in self.
+    class _Self(object):
+        fix_greedy_decoder = False
+    rng = np.random.default_rng(1009)
+    for order, tag in [(1, 'mono'), (2, 'bi')]:
+        me = _Self()
+        me.num_symbols = S
+        C = S ** order
+        me.blanks = [i for i in range(C) if i % S == 0]
+        B, T = 6, 14
+        frames = rng.integers(0, C, size=(B, T))
+        frames[0, :6] = [3, 3, 0, 3, 4, 4]
+        frames[1, 0] = frames[1, -1] = 5          # i == 0 vs last-frame quirk
+        frames[2, :] = 0
+        if order == 2:
+            frames[3, :5] = [S + 2, 2 * S + 2, 0, 3 * S + 2, 4]
+        flens = np.array([14, 14, 14, 9, 5, 1], np.int64)
+        dec = [[int(c) for c in ad.CTCDecoderAdvanced.process_sequence(
+                    me, t(frames[i]), t(flens)[i])] for i in range(B)]
+        out['greedy_%s_frames' % tag] = frames
+        out['greedy_%s_lens' % tag] = flens
+        out['greedy_%s_flat' % tag] = np.array(
+            [c for d in dec for c in d], np.int64)
+        out['greedy_%s_declens' % tag] = np.array([len(d) for d in dec], np.int64)
+    save('embedders_greedy.npz', **out)
+
+
+if __name__ == '__main__':
+    golden_lattice_mono()
+    golden_lattice_bigram()
+    golden_dense_bicontext()
+    golden_denominator()
+    golden_normalized_acts()
+    golden_embedders_and_greedy()
