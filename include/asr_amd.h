@@ -1,0 +1,138 @@
+/*
+ * include/asr_amd.h — C ABI of libasr_amd.so (MI355X / gfx950 HIP kernels).
+ *
+ * The reference (chorowski-lab/pytorch-asr) has no native code and no FFI for
+ * this path: its lattice arithmetic is Python-level torch code resolved by name
+ * (SURVEY.md §8b).  Each entry point below therefore replaces a *Python*
+ * function of the reference; the citation names the file:line (relative to the
+ * reference root) whose arithmetic the kernel reproduces.  INTEGRATION.md shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with h_;
+ *   - plain pointers and sizes only, no torch / HIP types (the stream is passed
+ *     as void* = hipStream_t);
+ *   - caller owns every buffer, the library never allocates, never
+ *     synchronises, and launches only on the passed stream (graph-capturable);
+ *   - return value: ASR_OK or an ASR_E* code; nothing is launched on error;
+ *   - tensors are dense row-major; log-probs are TIME-MAJOR [T,B,C] like the
+ *     reference (fst_utils.py:329);
+ *   - graph matrices are the reference's padded adjacency form
+ *     (fst_utils.py:222-294, 491-521) with int32 indices:
+ *     [Bg,N,K] with Bg == 1 (shared, e.g. the denominator graph,
+ *     fst_utils.py:662-676) or Bg == B; padding arcs carry weight <= neg_inf/2.
+ */
+#ifndef ASR_AMD_H
+#define ASR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    ASR_OK = 0,
+    ASR_EINVAL = 1,      /* bad shape / null pointer (reference: AssertionError) */
+    ASR_EUNSUPPORTED = 2,/* shape exceeds what the kernels are built for */
+    ASR_ELAUNCH = 3      /* HIP reported a launch error */
+};
+
+/* Library / ABI version, bumped when a signature changes. */
+int asr_abi_version(void);
+
+/* Human-readable text for an ASR_* code (static storage). */
+const char *asr_strerror(int code);
+
+/*
+ * Bytes of workspace asr_lattice_fwbw_f32 needs (alphas [T,B,N] f32 plus
+ * internal scratch).  Replaces the `lalphas` allocation of
+ * PathLogSumExp.forward (fst_utils.py:428).
+ */
+int64_t asr_lattice_fwbw_workspace_bytes(int T, int B, int C, int N);
+
+/*
+ * Log-semiring forward-backward over per-utterance lattices.
+ * Replaces PathLogSumExp.forward (fst_utils.py:403-480), reached through
+ * path_reduction(..., red_kind in {'logsumexp' with 8 matrices,
+ * 'logsumexp_fwb'}) (fst_utils.py:345-347).
+ *
+ *   lp        [T,B,C] f32   log-probs, time-major
+ *   lens      [B]     i32   active frames per utterance, 0 <= lens[b] <= T
+ *                           (the reference additionally requires them sorted
+ *                           descending, fst_utils.py:432; the kernel does not)
+ *   src_in/il_in/w_in   [Bg,N,Kin]  incoming arcs of each state
+ *   term                [Bg,N]      terminal log-weights
+ *   dst_out/il_out/w_out [Bg,N,Kout] outgoing arcs of each state
+ *   out_logZ  [B]     f32   +log-sum of all accepted paths (callers negate)
+ *   out_grad  [T,B,C] f32   d logZ[b] / d lp[t,b,c]; rows t >= lens[b] are
+ *                           written as zeros (fst_utils.py:448)
+ *   out_logZ_bwd [B] f32 or NULL: the backward-pass total used by the
+ *                           reference's consistency print (fst_utils.py:475-479)
+ *   workspace: asr_lattice_fwbw_workspace_bytes(T,B,C,N) bytes
+ */
+int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
+                         const int32_t *lens,
+                         const int32_t *src_in, const int32_t *il_in,
+                         const float *w_in, const float *term,
+                         const int32_t *dst_out, const int32_t *il_out,
+                         const float *w_out,
+                         int N, int Kin, int Kout, int Bg, float neg_inf,
+                         float *out_logZ, float *out_grad,
+                         float *out_logZ_bwd,
+                         void *workspace, int64_t workspace_bytes,
+                         void *stream);
+
+/*
+ * Alpha-only scan: path_reduction's autodiff branch evaluated forward
+ * (fst_utils.py:349-397) with reduction logsumexp (viterbi == 0) or max
+ * (viterbi == 1, fst_utils.py:366-370).
+ * For viterbi == 1 and out_best_il != NULL it also returns the input label of
+ * the best path's arc at every frame — what FSTDecoder.decode reads from the
+ * autograd gradient as `logits.grad.min(-1)[1]` (advanced_decoder.py:546-554);
+ * rows t >= lens[b] are 0.  Ties pick the first maximum.
+ *   out_score   [B]   f32
+ *   out_best_il [T,B] i32 or NULL
+ *   workspace: asr_lattice_viterbi_workspace_bytes(T,B,N) bytes when
+ *              out_best_il != NULL, else may be NULL.
+ */
+int64_t asr_lattice_viterbi_workspace_bytes(int T, int B, int N);
+
+int asr_lattice_forward_f32(const float *lp, int T, int B, int C,
+                            const int32_t *lens,
+                            const int32_t *src_in, const int32_t *il_in,
+                            const float *w_in, const float *term,
+                            int N, int K, int Bg, float neg_inf, int viterbi,
+                            float *out_score, int32_t *out_best_il,
+                            void *workspace, int64_t workspace_bytes,
+                            void *stream);
+
+/*
+ * Row-wise log-softmax over contiguous groups: x viewed as [rows, group],
+ * y = x - logsumexp(x, -1).  Replaces get_normalized_acts
+ * (modules/ctc_losses.py:29-43): group = C for the plain branch (:41-42),
+ * group = num_symbols for normalize_by_dim = context_order-1 (:34-40,
+ * the per-context block-wise normalisation over the last symbol axis).
+ */
+int asr_log_softmax_fwd_f32(const float *x, int64_t rows, int group,
+                            float *y, void *stream);
+
+/* dx = dy - exp(y) * sum(dy, -1)   (autograd of the above) */
+int asr_log_softmax_bwd_f32(const float *y, const float *dy, int64_t rows,
+                            int group, float *dx, void *stream);
+
+/*
+ * FSTDecoder.get_fst_loss's stabilisation (advanced_decoder.py:479-484):
+ *   row_max[t,b] = max_c x[t,b,c];  y = x - row_max;
+ *   max_sum[b]   = sum_{t < lens[b]} row_max[t,b]
+ * x, y [T,B,C]; row_max [T,B] (required, also the reduction scratch);
+ * max_sum [B], summed in a fixed order (bitwise reproducible).
+ */
+int asr_sub_rowmax_f32(const float *x, int T, int B, int C,
+                       const int32_t *lens, float *y, float *row_max,
+                       float *max_sum, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_AMD_H */

@@ -1,0 +1,199 @@
+"""ctypes binding of libasr_amd.so (include/asr_amd.h) for torch tensors.
+
+PyTorch is used here only as the owner of device memory and streams: every
+function takes CUDA(ROCm) tensors, passes raw device pointers + sizes + the
+current HIP stream through the C ABI, and returns tensors it allocated with
+torch.  There is NO CPU or eager fallback: a missing library or a non-GPU tensor
+raises immediately.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so')
+
+ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
+ABI_VERSION = 1
+
+_lib = None
+
+_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+_SIGNATURES = {
+    'asr_abi_version': (ctypes.c_int, []),
+    'asr_strerror': (ctypes.c_char_p, [_i]),
+    'asr_lattice_fwbw_workspace_bytes': (_i64, [_i, _i, _i, _i]),
+    'asr_lattice_fwbw_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp,
+                                  _vp, _i64, _vp]),
+    'asr_lattice_viterbi_workspace_bytes': (_i64, [_i, _i, _i]),
+    'asr_lattice_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                                     _i, _i, _i, _f, _i, _vp, _vp, _vp, _i64,
+                                     _vp]),
+    'asr_log_softmax_fwd_f32': (_i, [_vp, _i64, _i, _vp, _vp]),
+    'asr_log_softmax_bwd_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    'asr_sub_rowmax_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libasr_amd.so; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                "%s is missing: build it with `make -C pytorch-asr_amd/csrc` "
+                "(or __graft_entry__.build()); there is no fallback path."
+                % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.asr_abi_version() != ABI_VERSION:
+            raise NativeLibraryError("libasr_amd.so ABI %d != expected %d" % (
+                handle.asr_abi_version(), ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code == ASR_OK:
+        return
+    msg = "%s: %s" % (what, lib().asr_strerror(code).decode())
+    if code == ASR_EINVAL:
+        # the reference raises AssertionError / ValueError on malformed input
+        raise AssertionError(msg)
+    if code == ASR_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise NativeLibraryError(
+            "%s must be a GPU tensor: the MI355X path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Graph(object):
+    """Device-resident int32/f32 copy of the reference's 4 or 8 padded graph
+    matrices (fst_utils.py:222-294,491-521)."""
+    __slots__ = ('src_in', 'il_in', 'w_in', 'term', 'dst_out', 'il_out',
+                 'w_out', 'Bg', 'N', 'Kin', 'Kout')
+
+    def __init__(self, graph_matrices, device):
+        gm = list(graph_matrices)
+        if len(gm) not in (4, 8):
+            raise AssertionError("expected 4 or 8 graph matrices")
+        bg = gm[0].size(0)
+        if not all(m.size(0) == bg for m in gm):              # fst_utils.py:407
+            raise AssertionError("graph matrices disagree on batch size")
+
+        def to_i(m):
+            return m.to(device=device, dtype=torch.int32).contiguous()
+
+        def to_f(m):
+            return m.to(device=device, dtype=torch.float32).contiguous()
+        self.src_in, self.il_in, self.w_in = to_i(gm[0]), to_i(gm[1]), to_f(gm[2])
+        self.term = to_f(gm[3]).reshape(bg, -1)
+        self.Bg, self.N, self.Kin = self.src_in.shape
+        if len(gm) == 8:
+            self.dst_out, self.il_out, self.w_out = to_i(gm[4]), to_i(gm[5]), to_f(gm[6])
+            self.Kout = self.dst_out.shape[2]
+        else:
+            self.dst_out = self.il_out = self.w_out = None
+            self.Kout = 0
+
+
+def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
+    """asr_lattice_fwbw_f32: returns (logZ [B], grad [T,B,C], logZ_bwd|None)."""
+    lp = _dev(lp, torch.float32, 'log_probs')
+    lens = _dev(lens, torch.int32, 'act_lens')
+    T, B, C = lp.shape
+    if graph.Bg not in (1, B):
+        raise AssertionError("graph batch %d not in (1, %d)" % (graph.Bg, B))
+    L = lib()
+    logZ = torch.empty(B, dtype=torch.float32, device=lp.device)
+    grad = torch.empty_like(lp)
+    zb = torch.empty(B, dtype=torch.float32, device=lp.device) if want_bwd_total else None
+    nbytes = L.asr_lattice_fwbw_workspace_bytes(T, B, C, graph.N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=lp.device)
+    check(L.asr_lattice_fwbw_f32(
+        _p(lp), T, B, C, _p(lens), _p(graph.src_in), _p(graph.il_in),
+        _p(graph.w_in), _p(graph.term), _p(graph.dst_out), _p(graph.il_out),
+        _p(graph.w_out), graph.N, graph.Kin, graph.Kout, graph.Bg,
+        float(neg_inf), _p(logZ), _p(grad), _p(zb), _p(ws), nbytes, _stream()),
+        'asr_lattice_fwbw_f32')
+    return logZ, grad, zb
+
+
+def lattice_forward(lp, lens, graph, neg_inf=-1e20, viterbi=False, want_path=False):
+    """asr_lattice_forward_f32: returns (score [B], best_il [T,B] | None)."""
+    lp = _dev(lp, torch.float32, 'log_probs')
+    lens = _dev(lens, torch.int32, 'act_lens')
+    T, B, C = lp.shape
+    if graph.Bg not in (1, B):
+        raise AssertionError("graph batch %d not in (1, %d)" % (graph.Bg, B))
+    L = lib()
+    score = torch.empty(B, dtype=torch.float32, device=lp.device)
+    best, ws, nbytes = None, None, 0
+    if viterbi and want_path:
+        best = torch.empty((T, B), dtype=torch.int32, device=lp.device)
+        nbytes = L.asr_lattice_viterbi_workspace_bytes(T, B, graph.N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=lp.device)
+    check(L.asr_lattice_forward_f32(
+        _p(lp), T, B, C, _p(lens), _p(graph.src_in), _p(graph.il_in),
+        _p(graph.w_in), _p(graph.term), graph.N, graph.Kin, graph.Bg,
+        float(neg_inf), int(bool(viterbi)), _p(score), _p(best), _p(ws), nbytes,
+        _stream()), 'asr_lattice_forward_f32')
+    return score, best
+
+
+def log_softmax_fwd(x, group):
+    x = _dev(x, torch.float32, 'acts')
+    if x.numel() % group:
+        raise AssertionError("group %d does not divide %d" % (group, x.numel()))
+    y = torch.empty_like(x)
+    check(lib().asr_log_softmax_fwd_f32(_p(x), x.numel() // group, group, _p(y),
+                                        _stream()), 'asr_log_softmax_fwd_f32')
+    return y
+
+
+def log_softmax_bwd(y, dy, group):
+    y = _dev(y, torch.float32, 'y')
+    dy = _dev(dy, torch.float32, 'dy')
+    dx = torch.empty_like(y)
+    check(lib().asr_log_softmax_bwd_f32(_p(y), _p(dy), y.numel() // group, group,
+                                        _p(dx), _stream()),
+          'asr_log_softmax_bwd_f32')
+    return dx
+
+
+def sub_rowmax(x, lens):
+    """asr_sub_rowmax_f32: returns (x - rowmax, row_max [T,B], max_sum [B])."""
+    x = _dev(x, torch.float32, 'logits')
+    lens = _dev(lens, torch.int32, 'lens')
+    T, B, C = x.shape
+    y = torch.empty_like(x)
+    row_max = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    max_sum = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(lib().asr_sub_rowmax_f32(_p(x), T, B, C, _p(lens), _p(y), _p(row_max),
+                                   _p(max_sum), _stream()), 'asr_sub_rowmax_f32')
+    return y, row_max, max_sum

@@ -1,0 +1,537 @@
+"""att_speech.fst_utils — MI355X-native counterpart of the reference module of
+the same dotted name (reference: att_speech/fst_utils.py).
+
+Kept surface: path_reduction, path_logsumexp / PathLogSumExp,
+batch_training_graph_matrices, make_full_ngram_table, CTCGraphGen (context
+orders 1 and 2) with get_training_matrices(_batch) / get_decoding_matrices, the
+padded-adjacency matrix format of fst_to_matrices.
+
+What is different by design:
+  * the lattice arithmetic runs in hand-written gfx950 kernels behind the C ABI
+    (include/asr_amd.h) — there is no torch/CPU fallback;
+  * graphs are not built with OpenFst: the CTC training lattice
+    compose(decoding_fst, chain(labels)) and the decoding graphs have a closed
+    form which is generated directly, vectorised over the
+    batch, in the same state numbering a breadth-first OpenFst composition
+    yields ([blank0, l1, blank1, l2, ...]).
+"""
+from __future__ import absolute_import, division, print_function
+
+import numpy as np
+import torch
+
+from att_speech import _native
+
+NEG_INF = -1e20
+
+
+# ----------------------------------------------------------------------------
+# generic arc list -> padded adjacency matrices (reference fst_to_matrices,
+# fst_utils.py:222-294), vectorised with numpy
+# ----------------------------------------------------------------------------
+
+def _arcs_to_matrices(n_states, own, other, ilabel, weight, nc_weight):
+    """For each `own` state list its arcs sorted by (other, ilabel, weight)
+    (fst_utils.py:285), padded to the max degree with (0, 0, nc_weight)."""
+    own = np.asarray(own, np.int64)
+    other = np.asarray(other, np.int64)
+    ilabel = np.asarray(ilabel, np.int64)
+    weight = np.asarray(weight, np.float32)
+    order = np.lexsort((weight, ilabel, other, own))
+    own, other, ilabel, weight = own[order], other[order], ilabel[order], weight[order]
+    counts = np.bincount(own, minlength=n_states)
+    k = int(counts.max()) if len(own) else 0
+    k = max(k, 1)
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    slot = np.arange(len(own)) - starts[own]
+    states = np.zeros((n_states, k), np.int64)
+    ilabels = np.zeros((n_states, k), np.int64)
+    weights = np.full((n_states, k), nc_weight, np.float32)
+    states[own, slot] = other
+    ilabels[own, slot] = ilabel
+    weights[own, slot] = weight
+    return states, ilabels, weights
+
+
+def arcs_to_graph_matrices(n_states, src, dst, ilabel, weight, final_weight,
+                           nc_weight=NEG_INF, for_forward_only=False):
+    """Arc list (src -> dst consuming 0-based ilabel with log-weight) + final
+    log-weights -> the reference's 4 (in-edge) or 8 (in- then out-edge)
+    matrices, as torch CPU tensors (int64 / float32 like the reference)."""
+    term = np.asarray(final_weight, np.float32).reshape(n_states, 1)
+    mats = list(_arcs_to_matrices(n_states, dst, src, ilabel, weight, nc_weight))
+    mats.append(term)
+    if not for_forward_only:
+        mats += list(_arcs_to_matrices(n_states, src, dst, ilabel, weight, nc_weight))
+        mats.append(term.copy())
+    return tuple(torch.from_numpy(m) for m in mats)
+
+
+def in_to_out_edge_matrices(graph_matrices, nc_weight=NEG_INF):
+    """Given the 4 in-edge matrices [Bg,N,K] build the 4 out-edge ones (used
+    when a caller hands 4 matrices to a reduction that needs a backward pass:
+    the reference differentiates the alpha scan with autograd,
+    fst_utils.py:384-394; the kernels run an explicit beta scan instead)."""
+    s_i, l_i, w_i, term = [np.asarray(m.cpu()) for m in graph_matrices[:4]]
+    bg, n, k = s_i.shape
+    outs = []
+    kmax = 1
+    for g in range(bg):
+        valid = w_i[g] > nc_weight * 0.5
+        dst = np.repeat(np.arange(n), k).reshape(n, k)[valid]
+        o = _arcs_to_matrices(n, s_i[g][valid], dst, l_i[g][valid], w_i[g][valid],
+                              nc_weight)
+        outs.append(o)
+        kmax = max(kmax, o[0].shape[1])
+    so = np.zeros((bg, n, kmax), np.int64)
+    lo = np.zeros((bg, n, kmax), np.int64)
+    wo = np.full((bg, n, kmax), nc_weight, np.float32)
+    for g, (a, b, c) in enumerate(outs):
+        so[g, :, :a.shape[1]] = a
+        lo[g, :, :a.shape[1]] = b
+        wo[g, :, :a.shape[1]] = c
+    return (torch.from_numpy(so), torch.from_numpy(lo), torch.from_numpy(wo),
+            torch.from_numpy(term.copy()))
+
+
+# ----------------------------------------------------------------------------
+# lattice reductions on the GPU
+# ----------------------------------------------------------------------------
+
+def _lens_on(act_lens, device):
+    if not isinstance(act_lens, torch.Tensor):
+        act_lens = torch.as_tensor(act_lens)
+    return act_lens.to(device=device, dtype=torch.int32)
+
+
+def _assert_sorted(act_lens):
+    # fst_utils.py:382,432 — utterances are sorted by length, descending
+    l = act_lens.tolist() if isinstance(act_lens, torch.Tensor) else list(act_lens)
+    assert l == sorted(l, reverse=True)
+
+
+_graph_cache = {}
+
+
+def _device_graph(graph_matrices, device):
+    """Graph matrices arrive as CPU int64 tensors every step
+    (advanced_decoder.py:457-459); shared graphs (denominator) are the same
+    tensor objects each time and are converted once."""
+    if isinstance(graph_matrices, _native.Graph):
+        return graph_matrices
+    key = tuple((m.data_ptr(), m._version, tuple(m.shape)) for m in graph_matrices) + (str(device),)
+    hit = _graph_cache.get(key)
+    if hit is not None and all(a is b for a, b in zip(hit[0], graph_matrices)):
+        return hit[1]
+    g = _native.Graph(graph_matrices, device)
+    if graph_matrices[0].size(0) == 1:          # only shared graphs are worth caching
+        if len(_graph_cache) > 16:
+            _graph_cache.clear()
+        _graph_cache[key] = (list(graph_matrices), g)
+    return g
+
+
+class PathLogSumExp(torch.autograd.Function):
+    """Forward-backward in the log semiring; same contract as the reference's
+    PathLogSumExp (fst_utils.py:400-488): returns +logZ per utterance, the
+    gradient is computed inside forward and scaled in backward."""
+
+    @staticmethod
+    def forward(ctx, log_probs, act_lens, graph_matrices, neg_inf=-np.inf):
+        log_probs = log_probs.detach()
+        _assert_sorted(act_lens)
+        graph = _device_graph(graph_matrices, log_probs.device)
+        if graph.dst_out is None:
+            raise AssertionError("PathLogSumExp needs the 8 graph matrices")
+        if not np.isfinite(neg_inf):
+            neg_inf = NEG_INF
+        lens = _lens_on(act_lens, log_probs.device)
+        log_cost, grads, _ = _native.lattice_fwbw(log_probs, lens, graph, neg_inf)
+        ctx.grads = grads
+        return log_cost
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return (grad_output[None, :, None] * ctx.grads, None, None, None)
+
+
+path_logsumexp = PathLogSumExp.apply
+
+
+class _PathViterbi(torch.autograd.Function):
+    """max-plus alpha scan; d score / d log_probs is one-hot at the best path's
+    input label of every active frame (what autograd gives the reference,
+    fst_utils.py:366-370 + advanced_decoder.py:546-554)."""
+
+    @staticmethod
+    def forward(ctx, log_probs, act_lens, graph, neg_inf):
+        lens = _lens_on(act_lens, log_probs.device)
+        score, best = _native.lattice_forward(log_probs.detach(), lens, graph,
+                                              neg_inf, viterbi=True, want_path=True)
+        ctx.save_for_backward(best, lens)
+        ctx.shape = log_probs.shape
+        ctx.mark_non_differentiable(best)
+        return score, best
+
+    @staticmethod
+    def backward(ctx, grad_score, _grad_best):
+        best, lens = ctx.saved_tensors
+        T, B, C = ctx.shape
+        grad = torch.zeros(ctx.shape, dtype=grad_score.dtype, device=grad_score.device)
+        mask = (torch.arange(T, device=lens.device)[:, None] < lens[None, :])
+        vals = (grad_score[None, :] * mask).unsqueeze(-1)
+        grad.scatter_(2, best.long().unsqueeze(-1), vals)
+        return grad, None, None, None
+
+
+def viterbi_path(log_probs, act_lens, graph_matrices, neg_inf=NEG_INF):
+    """(score [B], best input label per frame [T,B] int32) of the best path."""
+    graph = _device_graph(graph_matrices, log_probs.device)
+    return _PathViterbi.apply(log_probs, act_lens, graph, neg_inf)
+
+
+def path_reduction(log_probs, act_lens, graph_matrices, red_kind='logsumexp',
+                   neg_inf=NEG_INF):
+    """Sum (logsumexp) or max over all paths through per-utterance graphs.
+    Same dispatch as the reference (fst_utils.py:322-397)."""
+    if (red_kind == 'logsumexp_fwb' or
+            (red_kind == 'logsumexp' and len(graph_matrices) == 8)):
+        return path_logsumexp(log_probs, act_lens, graph_matrices, NEG_INF)
+
+    _, bs, _ = log_probs.size()
+    assert graph_matrices[0].size(0) in [1, bs]
+    assert all(sm.size(0) == graph_matrices[0].size(0) for sm in graph_matrices)
+    _assert_sorted(act_lens)
+
+    if red_kind in ['logsumexp', 'logsumexp_autodiff']:
+        if not log_probs.requires_grad:
+            graph = _device_graph(graph_matrices[:4], log_probs.device)
+            lens = _lens_on(act_lens, log_probs.device)
+            return _native.lattice_forward(log_probs, lens, graph, neg_inf)[0]
+        # differentiable: explicit beta scan needs the out-edge form
+        if len(graph_matrices) == 4:
+            graph_matrices = list(graph_matrices) + list(
+                _cached_out_edges(graph_matrices, neg_inf))
+        return path_logsumexp(log_probs, act_lens, graph_matrices, neg_inf)
+    assert red_kind in ['viterbi', 'viterbi_autodiff']
+    return viterbi_path(log_probs, act_lens, graph_matrices[:4], neg_inf)[0]
+
+
+_out_edge_cache = {}
+
+
+def _cached_out_edges(graph_matrices, nc_weight):
+    key = tuple((m.data_ptr(), m._version, tuple(m.shape)) for m in graph_matrices[:4])
+    hit = _out_edge_cache.get(key)
+    if hit is None or not all(a is b for a, b in zip(hit[0], graph_matrices[:4])):
+        if len(_out_edge_cache) > 16:
+            _out_edge_cache.clear()
+        hit = (list(graph_matrices[:4]),
+               in_to_out_edge_matrices(graph_matrices, nc_weight))
+        _out_edge_cache[key] = hit
+    return hit[1]
+
+
+# ----------------------------------------------------------------------------
+# batching (reference fst_utils.py:491-521)
+# ----------------------------------------------------------------------------
+
+def batch_training_graph_matrices(matrices, nc_weight=NEG_INF, device='cpu'):
+    bs = len(matrices)
+    max_n = max([m[0].size(0) for m in matrices])
+    max_ks = [max([m[i].size(1) for m in matrices])
+              for i in range(len(matrices[0]))]
+    batched_matrices = []
+    for i, m in enumerate(matrices[0]):
+        batched_matrices.append(torch.full(
+            (bs, max_n, max_ks[i]),
+            0 if m.dtype == torch.int64 else nc_weight,
+            dtype=m.dtype, device=device))
+    for b, ms in enumerate(matrices):
+        for i, m in enumerate(ms):
+            batched_matrices[i][b, :m.size(0), :m.size(1)] = m
+    return batched_matrices
+
+
+def make_full_ngram_table(context_order, num_symbols, num_classes):
+    """reference fst_utils.py:524-534"""
+    if num_symbols is None:
+        num_symbols = int(round(num_classes ** (1.0 / context_order)))
+    num_classes = num_symbols ** context_order
+    idx = np.arange(num_classes)[:, None]
+    pw = num_symbols ** np.arange(context_order)[::-1][None, :]
+    ngram_to_class = torch.from_numpy((idx // pw % num_symbols).astype(np.int64))
+    return num_symbols, num_classes, ngram_to_class
+
+
+def setattr_matched(obj, var, val):
+    val_orig = getattr(obj, var)
+    if val_orig is not None:
+        assert val_orig == val, ("The value of %s is %s but should be %s" %
+                                 (var, val_orig, val))
+    else:
+        setattr(obj, var, val)
+
+
+# ----------------------------------------------------------------------------
+# closed-form CTC graphs
+# ----------------------------------------------------------------------------
+
+class DecodingTransducer(object):
+    """The CTC decoding FST (reference build_ctc_mono_decoding_fst
+    fst_utils.py:679-726 / build_ctc_bigram_decoding_fst :729-835) as a
+    transition function instead of an OpenFst object: input-deterministic, all
+    states final, start state 0.  `arcs()` enumerates (src, dst, ilabel0,
+    olabel) with 0-based input labels (arc.ilabel - 1, fst_utils.py:270)."""
+
+    def __init__(self, num_symbols, context_order, allow_nonblank_selfloops=True,
+                 use_contextual_blanks=False,
+                 loop_using_symbol_repetitions=False,
+                 eval_repeats_in_context=False):
+        assert not (eval_repeats_in_context and loop_using_symbol_repetitions)
+        assert not eval_repeats_in_context                     # fst_utils.py:760
+        if loop_using_symbol_repetitions:
+            raise NotImplementedError(
+                "loop_using_symbol_repetitions graphs are not built by the "
+                "closed-form generator (no shipped YAML uses them)")
+        self.S = num_symbols
+        self.context_order = context_order
+        self.allow_nonblank_selfloops = allow_nonblank_selfloops
+        self.use_contextual_blanks = use_contextual_blanks
+        self.num_states = num_symbols ** context_order
+
+    def arcs(self):
+        S = self.S
+        if self.context_order == 1:
+            src = np.repeat(np.arange(S), S)
+            dst = np.tile(np.arange(S), S)
+            il = dst.copy()
+            ol = np.where(src == dst, 0, dst)
+            return src, dst, il, ol
+        s1 = np.arange(S * S)
+        c1, l1 = s1 // S, s1 % S
+        c2 = np.where(l1 == 0, c1, l1)                          # (:798-801)
+        src = np.repeat(s1, S)
+        l2 = np.tile(np.arange(S), S * S)
+        c2r = np.repeat(c2, S)
+        dst = c2r * S + l2
+        il = np.where((l2 != 0) | self.use_contextual_blanks, c2r * S + l2, 0)
+        ol = np.where((l2 == 0) | (src == dst), 0, l2)
+        if self.allow_nonblank_selfloops:                       # (:791-795)
+            sl = s1[(l1 != 0) & (c1 != l1)]
+            src = np.concatenate([src, sl])
+            dst = np.concatenate([dst, sl])
+            il = np.concatenate([il, sl])
+            ol = np.concatenate([ol, np.zeros_like(sl)])
+        return src, dst, il, ol
+
+    def transition_tables(self):
+        """dense [num_states, num_classes] next-state / output tables
+        (-1 = no arc) for walking label sequences."""
+        if not hasattr(self, '_tables'):
+            C = self.S ** self.context_order
+            src, dst, il, ol = self.arcs()
+            nxt = np.full((self.num_states, C), -1, np.int64)
+            out = np.zeros((self.num_states, C), np.int64)
+            nxt[src, il] = dst
+            out[src, il] = ol
+            self._tables = (nxt, out)
+        return self._tables
+
+    def read_out(self, ilabels):
+        """Output labels produced while consuming 0-based input labels from
+        the start state — FSTDecoder.decode's compose + shortestpath read-out
+        (advanced_decoder.py:556-571)."""
+        nxt, out = self.transition_tables()
+        s, res = 0, []
+        for il in ilabels:
+            il = int(il)
+            ns = nxt[s, il]
+            if ns < 0:
+                return []
+            if out[s, il] > 0:
+                res.append(int(out[s, il]))
+            s = ns
+        return res
+
+
+def ctc_training_arcs(labels, label_lens, num_symbols, context_order,
+                      allow_nonblank_selfloops=True, use_contextual_blanks=False):
+    """Closed form of compose(decoding_fst, chain(labels)) for a whole batch.
+
+    labels [B,Lmax] (symbols, already reduced modulo num_symbols), label_lens
+    [B].  States of utterance b: 0 = initial blank, 2j+1 = label j, 2j+2 = the
+    blank after it; N_b = 2 L_b + 1.  Returns flat arrays
+    (b, src, dst, ilabel) and the per-utterance state counts."""
+    S = num_symbols
+    labels = np.asarray(labels, np.int64)
+    lens = np.asarray(label_lens, np.int64)
+    B, Lmax = labels.shape if labels.ndim == 2 else (len(lens), 0)
+    j = np.arange(Lmax)[None, :]
+    valid = j < lens[:, None]                                  # label j exists
+    l = np.where(valid, labels, 0)
+    ctx = np.concatenate([np.zeros((B, 1), np.int64), l[:, :-1]], 1) if Lmax else l
+    if context_order == 1:
+        emit = l
+        skip_ok = l[:, :-1] != l[:, 1:] if Lmax > 1 else np.zeros((B, 0), bool)
+        selfloop = np.ones_like(valid)
+        blank_of_label = np.zeros_like(l)       # blank after label j
+        blank0 = np.zeros(B, np.int64)
+    else:
+        emit = ctx * S + l
+        if Lmax > 1:
+            skip_ok = ~((ctx[:, :-1] == l[:, :-1]) & (l[:, :-1] == l[:, 1:]))
+        else:
+            skip_ok = np.zeros((B, 0), bool)
+        selfloop = np.full(valid.shape, bool(allow_nonblank_selfloops)) | (ctx == l)
+        blank_of_label = l * S if use_contextual_blanks else np.zeros_like(l)
+        blank0 = np.zeros(B, np.int64)
+    bb = np.broadcast_to(np.arange(B)[:, None], valid.shape)
+    jj = np.broadcast_to(j, valid.shape)
+    parts = []
+
+    def add(mask, src, dst, il):
+        parts.append((bb[mask], src[mask], dst[mask], il[mask]))
+    # blank -> next label   (2j -> 2j+1)
+    add(valid, 2 * jj, 2 * jj + 1, emit)
+    # label self-loop
+    add(valid & selfloop, 2 * jj + 1, 2 * jj + 1, emit)
+    # label -> following blank
+    add(valid, 2 * jj + 1, 2 * jj + 2, blank_of_label)
+    # following blank self-loop
+    add(valid, 2 * jj + 2, 2 * jj + 2, blank_of_label)
+    # label -> next label
+    if Lmax > 1:
+        m = valid[:, 1:] & skip_ok
+        parts.append((bb[:, :-1][m], (2 * jj[:, :-1] + 1)[m], (2 * jj[:, :-1] + 3)[m],
+                      emit[:, 1:][m]))
+    # initial blank self-loop
+    parts.append((np.arange(B), np.zeros(B, np.int64), np.zeros(B, np.int64), blank0))
+    b_, s_, d_, i_ = [np.concatenate(x) for x in zip(*parts)]
+    return b_, s_, d_, i_, 2 * lens + 1
+
+
+class BaseGraphGen(object):
+    """reference fst_utils.py:546-676 (grammar-FST composition excluded: it
+    needs an external LM FST)."""
+
+    def __init__(self, num_symbols=None, num_classes=None,
+                 ngram_to_class_file=None, context_order=None,
+                 nc_weight=NEG_INF, for_forward_only=False,
+                 grammar_fst=None, vocabulary=None, **kwargs):
+        super(BaseGraphGen, self).__init__(**kwargs)
+        if ngram_to_class_file is not None or grammar_fst is not None:
+            raise NotImplementedError(
+                "ngram_to_class_file / grammar_fst graphs need OpenFst")
+        self.num_classes = num_classes
+        self.num_symbols = num_symbols
+        self.context_order = context_order
+        if self.context_order is None:
+            self.context_order = 1
+        (num_symbols, num_classes, ngram_to_class) = make_full_ngram_table(
+            self.context_order, num_symbols, num_classes)
+        setattr_matched(self, 'num_symbols', num_symbols)
+        setattr_matched(self, 'num_classes', num_classes)
+        self.ngram_to_class = ngram_to_class
+        self.ngrams = ngram_to_class.tolist()
+        self.grammar_fst_path = None
+        self.nc_weight = nc_weight
+        self.decoding_fst = self.get_decoding_fst()
+        self.decoding_mats = {}
+        self.for_forward_only = for_forward_only
+
+    def get_decoding_fst(self):
+        return self.get_hc_fst()
+
+    def get_hc_fst(self):
+        raise NotImplementedError()
+
+    def _reduce_labels(self, labels):                           # (:592-600)
+        if isinstance(labels, torch.Tensor):
+            labels = labels.cpu().numpy()
+        labels = np.asarray(labels)
+        if np.any(labels > self.num_symbols):
+            labels = labels % self.num_symbols
+            if getattr(self, '_print_bigram_data_warn', True):
+                print("Got input symbol larger than num_symbols. "
+                      "Are you using a Bigram dataset with FSTs?")
+                self._print_bigram_data_warn = False
+        return labels
+
+    def get_training_matrices_batch(self, labels, label_lens, device='cpu'):
+        """(:607-613) — all utterances at once; returns 4 or 8 tensors
+        [B, maxN, K] padded like batch_training_graph_matrices."""
+        if isinstance(label_lens, torch.Tensor):
+            label_lens = label_lens.cpu().numpy()
+        label_lens = np.asarray(label_lens, np.int64)
+        B = len(label_lens)
+        if isinstance(labels, (list, tuple)):
+            lmax = int(label_lens.max()) if B else 0
+            lab = np.zeros((B, lmax), np.int64)
+            for i, row in enumerate(labels):
+                row = np.asarray(row.cpu() if isinstance(row, torch.Tensor) else row)
+                lab[i, :label_lens[i]] = row[:label_lens[i]]
+            labels = lab
+        labels = self._reduce_labels(labels)
+        labels = labels[:, :int(label_lens.max()) if B else 0]
+        d = self.decoding_fst
+        b_, s_, d_, i_, n_states = ctc_training_arcs(
+            labels, label_lens, self.num_symbols, self.context_order,
+            d.allow_nonblank_selfloops, d.use_contextual_blanks)
+        nmax = int(n_states.max())
+        w_ = np.zeros(len(b_), np.float32)
+        term = np.full((B, nmax, 1), self.nc_weight, np.float32)
+        bi = np.arange(B)
+        term[bi, n_states - 1, 0] = 0.0            # blank after the last label
+        has = label_lens > 0
+        term[bi[has], n_states[has] - 2, 0] = 0.0  # last label state
+        mats = self._batched(B, nmax, d_, s_, i_, w_, b_) + [torch.from_numpy(term)]
+        if not self.for_forward_only:
+            mats += self._batched(B, nmax, s_, d_, i_, w_, b_) + [
+                torch.from_numpy(term.copy())]
+        if str(device) != 'cpu':
+            mats = [m.to(device) for m in mats]
+        return mats
+
+    def _batched(self, B, nmax, own, other, il, w, b):
+        st, ilab, wt = _arcs_to_matrices(B * nmax, b * nmax + own, other, il, w,
+                                         self.nc_weight)
+        k = st.shape[1]
+        return [torch.from_numpy(st.reshape(B, nmax, k)),
+                torch.from_numpy(ilab.reshape(B, nmax, k)),
+                torch.from_numpy(wt.reshape(B, nmax, k))]
+
+    def get_training_matrices(self, labels, device='cpu'):      # (:647-660)
+        labels = np.asarray(labels.cpu() if isinstance(labels, torch.Tensor)
+                            else labels).reshape(1, -1)
+        mats = self.get_training_matrices_batch(labels, [labels.shape[1]], device)
+        return tuple(m[0] for m in mats)
+
+    def get_decoding_matrices(self, device='cpu', out_edges=False):  # (:662-676)
+        key = str(device)
+        ret = self.decoding_mats.get(key)
+        if ret is not None:
+            return ret
+        d = self.decoding_fst
+        src, dst, il, _ = d.arcs()
+        mats = arcs_to_graph_matrices(
+            d.num_states, src, dst, il, np.zeros(len(src), np.float32),
+            np.zeros(d.num_states, np.float32), self.nc_weight,
+            self.for_forward_only)
+        self.decoding_mats[key] = [m.unsqueeze(0).to(device) for m in mats]
+        return self.decoding_mats[key]
+
+
+class CTCGraphGen(BaseGraphGen):
+    """reference fst_utils.py:1053-1068 (context orders 1 and 2)."""
+
+    def __init__(self, context_order=None, graph_build_args=None, **kwargs):
+        assert context_order in (1, 2, 3)
+        if context_order == 3:
+            raise NotImplementedError("trigram CTC graphs are out of scope")
+        self.graph_build_args = graph_build_args or {}
+        super(CTCGraphGen, self).__init__(context_order=context_order, **kwargs)
+
+    def get_hc_fst(self):
+        args = self.graph_build_args if self.context_order == 2 else {}
+        return DecodingTransducer(self.num_symbols, self.context_order, **args)

@@ -1,0 +1,189 @@
+// Row-group log-softmax (forward / backward) and the per-frame max
+// stabilisation of FSTDecoder.get_fst_loss for gfx950.
+// Reference arithmetic: att_speech/modules/ctc_losses.py:29-43
+// (get_normalized_acts) and modules/decoders/advanced_decoder.py:479-484.
+//
+// HBM-bound streaming kernels: one 64-lane wave owns one row-group, lanes read
+// consecutive floats (coalesced 256 B per wave instruction), the group is kept
+// in registers between the reduction and the write, so every element is read
+// once and written once.
+#include "common.h"
+#include "../../include/asr_amd.h"
+
+namespace {
+
+using namespace asr;
+
+// PER = ceil(group / 64) elements per lane, compile-time so the row stays in
+// registers.
+template <int PER>
+__global__ void log_softmax_fwd_kernel(const float *__restrict__ x,
+                                       float *__restrict__ y, int64_t rows,
+                                       int group) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float *xr = x + r * group;
+        float v[PER];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int c = i * 64 + lane;
+            v[i] = c < group ? xr[c] : -INFINITY;
+            m = fmaxf(m, v[i]);
+        }
+        m = wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) s += __expf(v[i] - m);
+        s = wave_sum(s);
+        const float l = m + __logf(s);
+        float *yr = y + r * group;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int c = i * 64 + lane;
+            if (c < group) yr[c] = v[i] - l;
+        }
+    }
+}
+
+template <int PER>
+__global__ void log_softmax_bwd_kernel(const float *__restrict__ y,
+                                       const float *__restrict__ dy,
+                                       float *__restrict__ dx, int64_t rows,
+                                       int group) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float *yr = y + r * group;
+        const float *gr = dy + r * group;
+        float vy[PER], vg[PER];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int c = i * 64 + lane;
+            vy[i] = c < group ? yr[c] : -INFINITY;
+            vg[i] = c < group ? gr[c] : 0.f;
+            s += vg[i];
+        }
+        s = wave_sum(s);
+        float *dr = dx + r * group;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int c = i * 64 + lane;
+            if (c < group) dr[c] = vg[i] - __expf(vy[i]) * s;
+        }
+    }
+}
+
+// one wave per (t,b) row; the masked per-utterance sum of maxima is reduced
+// by max_sum_kernel in a fixed order (bitwise reproducible, no float atomics).
+template <int PER>
+__global__ void sub_rowmax_kernel(const float *__restrict__ x,
+                                  float *__restrict__ y,
+                                  float *__restrict__ row_max, int T, int B,
+                                  int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t rows = (int64_t)T * B;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float *xr = x + r * C;
+        float v[PER];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int c = i * 64 + lane;
+            v[i] = c < C ? xr[c] : -INFINITY;
+            m = fmaxf(m, v[i]);
+        }
+        m = wave_max(m);
+        float *yr = y + r * C;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int c = i * 64 + lane;
+            if (c < C) yr[c] = v[i] - m;
+        }
+        if (lane == 0) row_max[r] = m;
+    }
+}
+
+// max_sum[b] = sum_{t < lens[b]} row_max[t,b]; one wave per utterance.
+__global__ void max_sum_kernel(const float *__restrict__ row_max,
+                               const int32_t *__restrict__ lens,
+                               float *__restrict__ max_sum, int T, int B) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int len = lens[b];
+    len = len < 0 ? 0 : (len > T ? T : len);
+    float s = 0.f;
+    for (int t = lane; t < len; t += 64) s += row_max[(size_t)t * B + b];
+    s = wave_sum(s);
+    if (lane == 0) max_sum[b] = s;
+}
+
+inline int grid_for(int64_t rows) {
+    int64_t blocks = (rows + 3) / 4;       // 4 waves (rows) per 256-thread block
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+#define DISPATCH_PER(group, CALL)                       \
+    do {                                                \
+        int per_ = ((group) + 63) / 64;                 \
+        if (per_ <= 1) { CALL(1); }                     \
+        else if (per_ <= 2) { CALL(2); }                \
+        else if (per_ <= 4) { CALL(4); }                \
+        else if (per_ <= 8) { CALL(8); }                \
+        else if (per_ <= 16) { CALL(16); }              \
+        else if (per_ <= 40) { CALL(40); }              \
+        else if (per_ <= 128) { CALL(128); }            \
+        else return ASR_EUNSUPPORTED;                   \
+    } while (0)
+
+}  // namespace
+
+extern "C" int asr_log_softmax_fwd_f32(const float *x, int64_t rows, int group,
+                                       float *y, void *stream) {
+    if (rows < 0 || group <= 0) return ASR_EINVAL;
+    if (rows == 0) return ASR_OK;
+    if (!x || !y) return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(P) hipLaunchKernelGGL(log_softmax_fwd_kernel<P>, dim3(grid_for(rows)), dim3(256), 0, s, x, y, rows, group)
+    DISPATCH_PER(group, CALL);
+#undef CALL
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_log_softmax_bwd_f32(const float *y, const float *dy,
+                                       int64_t rows, int group, float *dx,
+                                       void *stream) {
+    if (rows < 0 || group <= 0) return ASR_EINVAL;
+    if (rows == 0) return ASR_OK;
+    if (!y || !dy || !dx) return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(P) hipLaunchKernelGGL(log_softmax_bwd_kernel<P>, dim3(grid_for(rows)), dim3(256), 0, s, y, dy, dx, rows, group)
+    DISPATCH_PER(group, CALL);
+#undef CALL
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_sub_rowmax_f32(const float *x, int T, int B, int C,
+                                  const int32_t *lens, float *y, float *row_max,
+                                  float *max_sum, void *stream) {
+    if (T < 0 || B < 0 || C <= 0) return ASR_EINVAL;
+    if (B == 0) return ASR_OK;
+    if (!lens || !max_sum) return ASR_EINVAL;
+    if (T > 0 && (!x || !y || !row_max)) return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rows = (int64_t)T * B;
+    if (T > 0) {
+#define CALL(P) hipLaunchKernelGGL(sub_rowmax_kernel<P>, dim3(grid_for(rows)), dim3(256), 0, s, x, y, row_max, T, B, C)
+        DISPATCH_PER(C, CALL);
+#undef CALL
+    }
+    hipLaunchKernelGGL(max_sum_kernel, dim3(B), dim3(64), 0, s, row_max, lens, max_sum, T, B);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}

@@ -1,0 +1,221 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI
+(att_speech._native -> libasr_amd.so), against (a) the committed golden vectors
+of the imported reference, (b) the CPU oracle on seeded inputs, (c) size-free
+properties at the benchmark's full sizes.
+
+Tolerances (north_star): loss within 1e-4 relative fp32; best-path label
+indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+LATTICES = ['lattice_mono', 'lattice_bigram_s7', 'lattice_bigram_s49',
+            'lattice_den_mono', 'lattice_den_bigram_s7']
+RTOL_LOSS = 1e-4
+ATOL_GRAD = 2e-5          # occupancies are in [0,1]
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device('cuda:0')
+
+
+def to_t(mats):
+    return [torch.from_numpy(np.ascontiguousarray(m)) for m in mats]
+
+
+def run_fwbw(lp, lens, mats, want_bwd=False):
+    from att_speech import _native
+    d = dev()
+    g = _native.Graph(to_t(mats), d)
+    logZ, grad, zb = _native.lattice_fwbw(
+        torch.from_numpy(lp).to(d), torch.from_numpy(np.asarray(lens, np.int32)).to(d),
+        g, -1e20, want_bwd_total=want_bwd)
+    torch.cuda.synchronize()
+    return logZ.cpu().numpy(), grad.cpu().numpy(), (zb.cpu().numpy() if want_bwd else None)
+
+
+def run_fwd(lp, lens, mats, viterbi):
+    from att_speech import _native
+    d = dev()
+    g = _native.Graph(to_t(mats[:4]), d)
+    s, best = _native.lattice_forward(
+        torch.from_numpy(lp).to(d), torch.from_numpy(np.asarray(lens, np.int32)).to(d),
+        g, -1e20, viterbi=viterbi, want_path=viterbi)
+    torch.cuda.synchronize()
+    return s.cpu().numpy(), (best.cpu().numpy() if best is not None else None)
+
+
+@pytest.mark.parametrize('name', LATTICES)
+def test_golden_fwbw(name):
+    g = golden(name + '.npz')
+    mats = [g['gm%d' % i] for i in range(8)]
+    logZ, grad, zb = run_fwbw(g['lp'], g['lens'], mats, want_bwd=True)
+    np.testing.assert_allclose(logZ, g['fwbw_logZ'], rtol=RTOL_LOSS)
+    np.testing.assert_allclose(grad, g['fwbw_grad'], atol=ATOL_GRAD)
+    assert np.abs(zb - logZ).max() < 1e-3                # fst_utils.py:475-479
+    for b, l in enumerate(g['lens']):
+        assert not grad[l:, b].any()                     # fst_utils.py:448
+
+
+@pytest.mark.parametrize('name', LATTICES)
+def test_golden_forward_and_viterbi(name):
+    g = golden(name + '.npz')
+    mats = [g['gm%d' % i] for i in range(8)]
+    s, _ = run_fwd(g['lp'], g['lens'], mats, viterbi=False)
+    np.testing.assert_allclose(s, g['autodiff_logZ'], rtol=RTOL_LOSS)
+    v, best = run_fwd(g['lp'], g['lens'], mats, viterbi=True)
+    np.testing.assert_allclose(v, g['viterbi_score'], rtol=1e-6)
+    for b, l in enumerate(g['lens']):                    # bit-exact indices
+        np.testing.assert_array_equal(best[:l, b], g['viterbi_selidx'][:l, b])
+        assert not best[l:, b].any()
+
+
+def _random_case(order, S, T, B, Lmax, seed, kind='num', lens=None):
+    from att_speech import fst_utils as P
+    rng = np.random.default_rng(seed)
+    C = S ** order
+    if lens is None:
+        lens = np.sort(rng.integers(max(1, T // 2), T + 1, size=B))[::-1].copy()
+        lens[0] = T
+    lens = np.asarray(lens, np.int32)
+    x = rng.standard_normal((T, B, C)).astype(np.float32) * 2
+    pg = P.CTCGraphGen(context_order=order, num_symbols=S)
+    if kind == 'num':
+        lp = torch.log_softmax(torch.from_numpy(x), -1).numpy()
+        llens = rng.integers(0, Lmax + 1, size=B)
+        llens[0] = Lmax
+        labs = rng.integers(1, S, size=(B, Lmax))
+        mats = [m.numpy() for m in pg.get_training_matrices_batch(labs, llens)]
+    else:
+        lp = x - x.max(-1, keepdims=True)
+        mats = [m.numpy() for m in pg.get_decoding_matrices()]
+    return lp, lens, mats
+
+
+CASES = [
+    ('mono_num', dict(order=1, S=49, T=120, B=9, Lmax=40, seed=1)),
+    ('mono_num_long', dict(order=1, S=49, T=700, B=3, Lmax=330, seed=2)),   # N=661 > 512
+    ('bi_num', dict(order=2, S=49, T=60, B=5, Lmax=20, seed=3)),
+    ('mono_den', dict(order=1, S=49, T=50, B=4, Lmax=0, seed=4, kind='den')),
+    ('bi_den_s7', dict(order=2, S=7, T=50, B=4, Lmax=0, seed=5, kind='den')),
+    ('bi_den_s49', dict(order=2, S=49, T=12, B=2, Lmax=0, seed=6, kind='den')),  # 2401 x 51
+    ('ragged', dict(order=1, S=49, T=30, B=6, Lmax=8, seed=7,
+                    lens=[30, 30, 17, 2, 1, 0])),
+    ('single', dict(order=1, S=49, T=1, B=1, Lmax=1, seed=8, lens=[1])),
+]
+
+
+@pytest.mark.parametrize('name,kw', CASES, ids=[c[0] for c in CASES])
+def test_seeded_vs_oracle(oracle_lib, name, kw):
+    lp, lens, mats = _random_case(**kw)
+    want = oracle_lib.path_logsumexp(lp, lens, mats)
+    logZ, grad, zb = run_fwbw(lp, lens, mats, want_bwd=True)
+    np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
+    np.testing.assert_allclose(grad, want['grad'], atol=ATOL_GRAD)
+    np.testing.assert_allclose(zb, want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
+    s, _ = run_fwd(lp, lens, mats, viterbi=False)
+    np.testing.assert_allclose(s, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
+    vs, vil = oracle_lib.path_forward(lp, lens, mats, viterbi=True)
+    v, best = run_fwd(lp, lens, mats, viterbi=True)
+    np.testing.assert_allclose(v, vs, rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(best, vil)            # bit-exact, incl. padding rows
+
+
+def test_full_size_properties():
+    """BASELINE shape (T'=334, C=49, L<=100) at a saturating batch: properties
+    that need no oracle — per-frame posteriors sum to one, zero rows past the
+    end, forward total == backward total, == torch's own CTC on the GPU."""
+    from att_speech import fst_utils as P
+    B, T, S = 256, 334, 49
+    rng = np.random.default_rng(99)
+    lens = np.array([T - (b % 64) for b in range(B)], np.int32)
+    lens = np.sort(lens)[::-1].copy()
+    llens = np.array([100 - 2 * (b % 16) for b in range(B)])
+    labs = rng.integers(2, 49, size=(B, 100))
+    lp = torch.log_softmax(torch.from_numpy(
+        rng.standard_normal((T, B, S)).astype(np.float32)), -1)
+    pg = P.CTCGraphGen(context_order=1, num_symbols=S)
+    mats = [m.numpy() for m in pg.get_training_matrices_batch(labs, llens)]
+    logZ, grad, zb = run_fwbw(lp.numpy(), lens, mats, want_bwd=True)
+    np.testing.assert_allclose(zb, logZ, rtol=RTOL_LOSS)
+    mask = (np.arange(T)[:, None] < lens[None, :])
+    np.testing.assert_allclose(grad.sum(-1)[mask], 1.0, atol=1e-4)
+    assert not grad[~mask].any()
+    assert grad.min() >= 0.0
+    want = torch.nn.functional.ctc_loss(
+        lp.to(dev()), torch.from_numpy(labs).to(dev()), torch.from_numpy(lens).long(),
+        torch.from_numpy(llens), reduction='none').cpu().numpy()
+    np.testing.assert_allclose(-logZ, want, rtol=RTOL_LOSS)
+
+
+def test_path_reduction_surface():
+    """att_speech.fst_utils.path_reduction keeps the reference's dispatch,
+    autograd behaviour and error checks (fst_utils.py:322-397, 482-485)."""
+    from att_speech import fst_utils as P
+    g = golden('lattice_mono.npz')
+    d = dev()
+    mats = to_t([g['gm%d' % i] for i in range(8)])
+    lens = torch.from_numpy(g['lens'])
+    lp = torch.from_numpy(g['lp']).to(d).requires_grad_()
+    z = P.path_reduction(lp, lens, mats, red_kind='logsumexp')
+    w = torch.from_numpy(g['w']).to(d)
+    (z * w).sum().backward()
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g['fwbw_logZ'], rtol=RTOL_LOSS)
+    np.testing.assert_allclose(lp.grad.cpu().numpy(), g['fwbw_grad_w'], atol=ATOL_GRAD)
+    # 4 matrices + autodiff request -> still differentiable
+    lp2 = torch.from_numpy(g['lp']).to(d).requires_grad_()
+    z2 = P.path_reduction(lp2, lens, mats[:4], red_kind='logsumexp_autodiff')
+    z2.sum().backward()
+    np.testing.assert_allclose(lp2.grad.cpu().numpy(), g['autodiff_grad'], atol=1e-4)
+    # viterbi: gradient is the one-hot best path; selidx recipe of the decoder
+    lp3 = torch.from_numpy(g['lp']).to(d).requires_grad_()
+    v = P.path_reduction(lp3, lens, mats[:4], red_kind='viterbi')
+    (-v.sum()).backward()
+    sel = lp3.grad.min(-1)[1].cpu().numpy()
+    for b, l in enumerate(g['lens']):
+        np.testing.assert_array_equal(sel[:l, b], g['viterbi_selidx'][:l, b])
+    # unsorted lengths are refused like the reference (fst_utils.py:382,432)
+    with pytest.raises(AssertionError):
+        P.path_reduction(lp, torch.flip(lens, [0]), mats)
+    # CPU tensors: no fallback
+    from att_speech import _native
+    with pytest.raises(_native.NativeLibraryError):
+        P.path_reduction(torch.from_numpy(g['lp']), lens, mats)
+
+
+def test_log_softmax_and_rowmax(oracle_lib):
+    from att_speech import _native
+    d = dev()
+    g = golden('normalized_acts.npz')
+    S = int(g['S'])
+    x = torch.from_numpy(g['acts']).to(d)
+    np.testing.assert_allclose(_native.log_softmax_fwd(x, S * S).cpu().numpy(),
+                               g['zero'], atol=2e-6)
+    np.testing.assert_allclose(_native.log_softmax_fwd(x, S).cpu().numpy(),
+                               g['one'], atol=2e-6)
+    rng = np.random.default_rng(3)
+    for rows, group in [(1000, 49), (37, 2401), (5, 1), (64, 64), (3, 130), (2, 5000)]:
+        a = (rng.standard_normal((rows, group)) * 4).astype(np.float32)
+        ta = torch.from_numpy(a).to(d)
+        y = _native.log_softmax_fwd(ta, group)
+        np.testing.assert_allclose(y.cpu().numpy(), oracle_lib.log_softmax(a), atol=5e-6)
+        dy = torch.from_numpy(rng.standard_normal((rows, group)).astype(np.float32)).to(d)
+        dx = _native.log_softmax_bwd(y, dy, group)
+        tr = ta.clone().requires_grad_()
+        torch.log_softmax(tr, -1).backward(dy)
+        np.testing.assert_allclose(dx.cpu().numpy(), tr.grad.cpu().numpy(), atol=2e-5)
+    # advanced_decoder.py:479-484
+    T, B, C = 50, 7, 49
+    a = rng.standard_normal((T, B, C)).astype(np.float32)
+    lens = np.array([50, 44, 30, 30, 9, 1, 0], np.int32)
+    y, rmax, msum = _native.sub_rowmax(torch.from_numpy(a).to(d),
+                                       torch.from_numpy(lens).to(d))
+    np.testing.assert_array_equal(rmax.cpu().numpy(), a.max(-1))
+    np.testing.assert_array_equal(y.cpu().numpy(), a - a.max(-1, keepdims=True))
+    mask = np.arange(T)[:, None] < lens[None, :]
+    np.testing.assert_allclose(msum.cpu().numpy(), (a.max(-1) * mask).sum(0), rtol=1e-5, atol=1e-5)
