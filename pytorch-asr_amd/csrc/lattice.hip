@@ -7,6 +7,8 @@
 // buffered, one s_barrier per frame); the per-frame gradient row is
 // accumulated in LDS (ds_add_f32) and streamed out coalesced, so every
 // [t,b,:] row of the dense gradient is written exactly once.
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/asr_amd.h"
 
@@ -26,6 +28,7 @@ struct FwbwParams {
     float neg_inf;
     float *logZ, *grad, *logZ_bwd;
     float *alphas;  // [T,B,N]
+    int32_t *flags; // [B] 1 = utterance left to the generic kernel (may be null)
 };
 
 // KR > 0: every thread owns ONE state (N <= blockDim) and keeps its <= KR
@@ -229,6 +232,702 @@ __global__ void lattice_fwbw_kernel(FwbwParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Meet-in-the-middle forward-backward for small-degree graphs (the CTC
+// numerator lattices: N <= 512 states, <= KR arcs per state).
+//
+// The alpha recurrence and the beta recurrence are independent, so the
+// workgroup runs them CONCURRENTLY: threads [0,H) ("A group") scan alpha
+// forward from frame 0, threads [H,2H) ("B group") scan beta backward from
+// frame len-1; each owns one state and keeps its arcs in registers.  They meet
+// at m = len/2, where logZ = logsumexp_n(alpha_m + beta_m) is known, and keep
+// going: past the meeting point the A group has beta_{t+1} (stored by the B
+// group on its way down) and the B group has alpha_t, so each turns its own
+// arc tokens into occupancies on the fly.  The sequential depth is len steps
+// instead of 2*len, with one s_barrier per step.
+//
+// Emissions lp[t,b,il] do not depend on the recurrence: they are fetched D
+// frames ahead into a register ring (the barrier is a bare s_barrier +
+// lgkmcnt(0), so the loads stay in flight across it).
+//
+// Workspace ws[t,b,n]: alpha_t[n] for t < m, beta_{t+1}[n] for t >= m.
+// ---------------------------------------------------------------------------
+#ifdef ASR_ABLATE_NOEMIT
+#define EMIT_LOAD(t, k) (-1.f - 0.001f * (float)r_il[k])
+#else
+#define EMIT_LOAD(t, k) lp_b[(size_t)(t) * tstride + r_il[k]]
+#endif
+#ifdef ASR_ABLATE_NOWS
+#define WS_STORE(t, val) do { if ((val) == 123.f) ws_b[0] = 0.f; } while (0)
+#define WS_LOAD(t) (-3.f)
+#else
+#define WS_STORE(t, val) ws_b[(size_t)(t) * astride + n] = (val)
+#define WS_LOAD(t) ws_b[(size_t)(t) * astride + n]
+#endif
+template <int KR, int D>
+__global__ __launch_bounds__(1024) void lattice_fwbw_mitm_kernel(FwbwParams p) {
+    extern __shared__ float smem[];
+    const int b = blockIdx.x;
+    if (p.flags && p.flags[b] == 0) return;          // done by the fast path
+    const int H = blockDim.x >> 1;
+    const int grp = threadIdx.x >= H ? 1 : 0;        // wave-uniform (H % 64 == 0)
+    const int n = threadIdx.x - grp * H;
+    const int N = p.N, C = p.C;
+    const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
+    float *sbuf = smem + grp * 2 * Npad;             // [2][Npad] alpha | beta
+    float *row = smem + 4 * Npad + grp * 2 * Cpad;   // [2][Cpad] per group
+    float *red = smem + 4 * Npad + 4 * Cpad;         // [32]
+
+    const int g = (p.Bg == 1) ? 0 : b;
+    const int K = grp ? p.Kout : p.Kin;
+    const int32_t *oth = (grp ? p.dst_out : p.src_in) + (size_t)g * N * K;
+    const int32_t *ilp = (grp ? p.il_out : p.il_in) + (size_t)g * N * K;
+    const float *wp = (grp ? p.w_out : p.w_in) + (size_t)g * N * K;
+    const float *term = p.term + (size_t)g * N;
+    int len = p.lens[b];
+    len = len < 0 ? 0 : (len > p.T ? p.T : len);
+    const int m = len >> 1;          // meeting frame
+    const int P = len - m;           // iterations per phase (>= m)
+    const size_t tstride = (size_t)p.B * C;
+    const float *lp_b = p.lp + (size_t)b * C;
+    float *grad_b = p.grad + (size_t)b * C;
+    const size_t astride = (size_t)p.B * N;
+    float *ws_b = p.alphas + (size_t)b * N;
+    const float half_inf = p.neg_inf * 0.5f;
+    const bool own = n < N;
+
+    for (int t = len; t < p.T; ++t)                  // fst_utils.py:448
+        for (int c = threadIdx.x; c < C; c += blockDim.x)
+            grad_b[(size_t)t * tstride + c] = 0.f;
+
+    int r_oth[KR], r_il[KR];
+    float r_w[KR];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        bool v = own && k < K;
+        r_oth[k] = v ? oth[n * K + k] : 0;
+        r_il[k] = v ? ilp[n * K + k] : 0;
+        r_w[k] = v ? wp[n * K + k] : p.neg_inf;
+    }
+    // alpha_0 = [0, neg_inf, ...]; beta_len = terminal
+    for (int i = n; i < Npad; i += H)
+        sbuf[i] = grp ? (i < N ? term[i] : p.neg_inf) : (i == 0 ? 0.f : p.neg_inf);
+    for (int c = n; c < 2 * Cpad; c += H) row[c] = 0.f;
+    __syncthreads();
+
+    // frame visited by this group at iteration j of phase ph (-1: idle)
+    //   A: phase 0 -> j (j < m)        phase 1 -> m + j
+    //   B: phase 0 -> len-1-j          phase 1 -> m-1-j (j < m)
+    auto frame_of = [&](int ph, int j) -> int {
+        if (grp == 0) return ph == 0 ? (j < m ? j : -1) : m + j;
+        return ph == 0 ? len - 1 - j : (j < m ? m - 1 - j : -1);
+    };
+
+    float e[D][KR];
+    float wsr[D];
+    int cur = 0;
+
+    // ================= phase 0: plain scans, store alpha_t / beta_{t+1} =====
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        int t = u < P ? frame_of(0, u) : -1;
+#pragma unroll
+        for (int k = 0; k < KR; ++k)
+            e[u][k] = t >= 0 ? EMIT_LOAD(t, k) : 0.f;
+    }
+    for (int j0 = 0; j0 < P; j0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int j = j0 + u;
+            if (j < P) {
+                const int t = frame_of(0, j);
+                if (t >= 0 && own) {
+                    const float *s = sbuf + cur * Npad;
+                    WS_STORE(t, s[n]);
+                    float v[KR];
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < KR; ++k) {
+                        v[k] = r_w[k] + s[r_oth[k]] + e[u][k];
+                        mx = fmaxf(mx, v[k]);
+                    }
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KR; ++k) sum += __expf(v[k] - mx);
+                    sbuf[(cur ^ 1) * Npad + n] = mx + __logf(sum);
+                }
+                const int tn = (j + D < P) ? frame_of(0, j + D) : -1;
+#pragma unroll
+                for (int k = 0; k < KR; ++k)
+                    e[u][k] = tn >= 0 ? EMIT_LOAD(tn, k) : 0.f;
+                if (t >= 0) cur ^= 1;
+                __syncthreads();
+            }
+        }
+    }
+
+    // ================= meeting point ========================================
+    // prime phase-1 rings first so the loads fly during the reduction
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        int t = u < P ? frame_of(1, u) : -1;
+#pragma unroll
+        for (int k = 0; k < KR; ++k)
+            e[u][k] = t >= 0 ? EMIT_LOAD(t, k) : 0.f;
+        wsr[u] = (t >= 0 && own) ? WS_LOAD(t) : 0.f;
+    }
+    float logZm;
+    // both groups need to know which buffer the other group ended on: A made
+    // m updates, B made P updates, both starting at buffer 0.
+    const int curA = m & 1, curB = P & 1;
+    {
+        const float *al = smem + curA * Npad;
+        const float *be = smem + 2 * Npad + curB * Npad;
+        float mx = -INFINITY;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) mx = fmaxf(mx, al[i] + be[i]);
+        mx = block_max(mx, red);
+        float sum = 0.f;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) sum += __expf(al[i] + be[i] - mx);
+        sum = block_sum(sum, red);
+        logZm = mx + __logf(sum);
+    }
+    __syncthreads();
+
+    // ================= phase 1: scans + occupancies =========================
+    int rc = 0;
+    for (int j0 = 0; j0 < P; j0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int j = j0 + u;
+            if (j < P) {
+                const int t = frame_of(1, j);
+                if (t >= 0) {
+                    // flush the row finished one step ago, re-zero it
+                    if (j > 0) {
+                        const int tp = grp == 0 ? t - 1 : t + 1;
+                        float *gout = grad_b + (size_t)tp * tstride;
+                        float *rp = row + (rc ^ 1) * Cpad;
+                        for (int c = n; c < C; c += H) {
+                            gout[c] = rp[c];
+                            rp[c] = 0.f;
+                        }
+                    }
+                    if (own) {
+                        const float *s = sbuf + cur * Npad;
+                        float *rw = row + rc * Cpad;
+                        float v[KR];
+                        float mx = -INFINITY;
+#pragma unroll
+                        for (int k = 0; k < KR; ++k) {
+                            v[k] = r_w[k] + s[r_oth[k]] + e[u][k];
+                            mx = fmaxf(mx, v[k]);
+                        }
+                        float sum = 0.f;
+#pragma unroll
+                        for (int k = 0; k < KR; ++k) sum += __expf(v[k] - mx);
+                        sbuf[(cur ^ 1) * Npad + n] = mx + __logf(sum);
+                        const float a = wsr[u] - logZm;
+#pragma unroll
+                        for (int k = 0; k < KR; ++k) {
+                            if (r_w[k] > half_inf) {
+                                float o = __expf(v[k] + a);
+#ifndef ASR_ABLATE_NOATOMIC
+                                if (o != 0.f) atomicAdd(&rw[r_il[k]], o);
+#else
+                                if (o == 123.f) rw[0] = o;
+#endif
+                            }
+                        }
+                    }
+                }
+                const int tn = (j + D < P) ? frame_of(1, j + D) : -1;
+#pragma unroll
+                for (int k = 0; k < KR; ++k)
+                    e[u][k] = tn >= 0 ? EMIT_LOAD(tn, k) : 0.f;
+                wsr[u] = (tn >= 0 && own) ? WS_LOAD(tn) : 0.f;
+                if (t >= 0) { cur ^= 1; rc ^= 1; }
+                __syncthreads();
+            }
+        }
+    }
+    // flush each group's last row: A ends on frame len-1, B on frame 0
+    {
+        const int steps = grp == 0 ? P : m;
+        if (steps > 0) {
+            const int tl = grp == 0 ? len - 1 : 0;
+            float *gout = grad_b + (size_t)tl * tstride;
+            const float *rp = row + (rc ^ 1) * Cpad;
+            for (int c = n; c < C; c += H) gout[c] = rp[c];
+        }
+    }
+    // logZ = logsumexp_n(alpha_len + terminal) (fst_utils.py:445); A made len
+    // updates in total.  logZ_bwd from beta_0 (fst_utils.py:476).
+    {
+        const float *al = smem + (len & 1) * Npad;
+        float mx = -INFINITY;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) mx = fmaxf(mx, al[i] + term[i]);
+        mx = block_max(mx, red);
+        float sum = 0.f;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) sum += __expf(al[i] + term[i] - mx);
+        sum = block_sum(sum, red);
+        if (threadIdx.x == 0) p.logZ[b] = mx + __logf(sum);
+    }
+    if (p.logZ_bwd) {
+        const float *be = smem + 2 * Npad + (len & 1) * Npad;
+        float mx = -INFINITY;
+        for (int i = threadIdx.x; i < N; i += blockDim.x)
+            mx = fmaxf(mx, be[i] + (i == 0 ? 0.f : p.neg_inf));
+        mx = block_max(mx, red);
+        float sum = 0.f;
+        for (int i = threadIdx.x; i < N; i += blockDim.x)
+            sum += __expf(be[i] + (i == 0 ? 0.f : p.neg_inf) - mx);
+        sum = block_sum(sum, red);
+        if (threadIdx.x == 0) p.logZ_bwd[b] = mx + __logf(sum);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fast path for STATE-LABELLED graphs: every valid in-arc of a state carries
+// the same input label.  True for all CTC lattices of the reference (a state
+// of compose(decoding_fst, chain) is "the last emitted class", fst_utils.py:
+// 679-835) and checked per utterance at kernel entry; a graph that fails the
+// check sets flags[b] = 1 and is left to the generic kernel launched behind.
+//
+// With one label per state
+//   alpha_{t+1}[n] = lp_t[label n] + LSE_k(w_k + alpha_t[src_k])
+//   beta_t[n]      = LSE_k(w_k + (beta_{t+1} + lp_t[label .])[dst_k])
+//   d logZ / d lp_t[c] = sum_{n: label n = c} exp(alpha_{t+1}[n] + beta_{t+1}[n] - logZ)
+// i.e. ONE emission fetch, ONE posterior exp and ONE LDS add per state and
+// frame instead of one per arc.  Same meet-in-the-middle schedule as
+// lattice_fwbw_mitm_kernel.  All scores are kept in log2 units so the
+// recurrences use the raw v_exp_f32 / v_log_f32 (no range-reduction code);
+// results are converted back on output.  The label shared by most lanes of a
+// wave (the blank, label of lane 0's state) is reduced with DPP before the LDS
+// add so it costs one ds_add per wave instead of a 32-way same-address add.
+//
+// ws[t,b,n] (log2 units): alpha_{t+1}[n] for t < m, beta_{t+1}[n] for t >= m.
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    int x = __builtin_bit_cast(int, v);
+    int y = __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(float, y);
+}
+
+// sum over the 64 lanes, result valid in every lane
+__device__ __forceinline__ float dpp_wave_sum(float v) {
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror  -> 16-lane row sums
+    int x = __builtin_bit_cast(int, v);
+    float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
+    float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+    float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32));
+    float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+#ifdef ASR_SL_NOBAR
+#define SL_BARRIER() do {} while (0)
+#else
+#define SL_BARRIER() __syncthreads()
+#endif
+#define ASR_L2E 1.4426950408889634f
+#define ASR_LN2 0.6931471805599453f
+
+template <int K, int D, int FL>
+__global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
+    // FL == 1: C <= H, the per-step row flush is one store per lane;
+    // FL == 0: runtime flush loop (large C, bandwidth-bound regime).
+    extern __shared__ float smem[];
+    typedef unsigned int u32;
+    const int b = blockIdx.x;
+    const int H = blockDim.x >> 1;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >= (unsigned)H ? 1 : 0);
+    const int n = threadIdx.x - grp * H;
+    const int N = p.N, C = p.C;
+    const int Cpad = (C + 3) & ~3;
+    float *sbuf = smem + grp * 2 * H;                 // [2][H] alpha | beta~
+    float *row = smem + 4 * H + grp * 3 * Cpad;       // [3][Cpad] rotating
+    float *red = smem + 4 * H + 6 * Cpad;             // [32]
+    float *ldump = red + 64 + grp * H + n;            // lane-private sink for masked LDS ops
+
+    const int g = (p.Bg == 1) ? 0 : b;
+    const int Kin = p.Kin, Kout = p.Kout;
+    const int32_t *il_in = p.il_in + (size_t)g * N * Kin;
+    const float *w_in = p.w_in + (size_t)g * N * Kin;
+    const float *term = p.term + (size_t)g * N;
+    const float half_inf = p.neg_inf * 0.5f;
+    const float NI2 = p.neg_inf * ASR_L2E;
+    const bool own = n < N;
+
+    // ---- state-labelled check -------------------------------------------
+    int label = 0;
+    bool ok = true;
+    if (own) {
+        label = il_in[n * Kin];
+        for (int k = 1; k < Kin; ++k)
+            if (w_in[n * Kin + k] > half_inf && il_in[n * Kin + k] != label) ok = false;
+    }
+    if (!__syncthreads_and(ok)) {
+        if (threadIdx.x == 0) p.flags[b] = 1;
+        return;
+    }
+    if (threadIdx.x == 0) p.flags[b] = 0;
+
+    int len = p.lens[b];
+    len = len < 0 ? 0 : (len > p.T ? p.T : len);
+    const int m = len >> 1;                  // joint steps per phase
+    const int solo = len - 2 * m;            // 1 if len is odd
+    const int r = m % D, q = m / D;
+    const size_t tstride = (size_t)p.B * C;
+    float *grad_b = p.grad + (size_t)b * C;
+
+    for (int t = len; t < p.T; ++t)                  // fst_utils.py:448
+        for (int c = threadIdx.x; c < C; c += blockDim.x)
+            grad_b[(size_t)t * tstride + c] = 0.f;
+
+    // ---- buffer resources: every global access of the scan goes through a
+    // bounds-checked raw buffer with a per-lane 32-bit byte offset, so the
+    // prefetch may run past either end of the utterance (out-of-range loads
+    // return 0, out-of-range stores are dropped) and masked-off lanes simply
+    // carry an out-of-range offset.  No clamps, no conditional VMEM: the
+    // steady-state loop has an exact VMEM count per step and hipcc emits
+    // counted vmcnt(N) waits.
+    // workspace [T+2, B, H] (log2 units): slot t < m: alpha_{t+1};
+    // slot t in [m, len]: beta_t.
+    const u32 ts4 = (u32)tstride * 4u;               // frame stride of lp / grad, bytes
+    const u32 as4 = (u32)p.B * (u32)H * 4u;          // slot stride of ws, bytes
+    const u32 lp_bytes = (u32)(((size_t)p.T * p.B * C - (size_t)b * C) * 4);
+    const u32 ws_bytes = (u32)(((size_t)(p.T + 2) * p.B * H - (size_t)b * H) * 4);
+    const __amdgpu_buffer_rsrc_t lpR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.lp) + (size_t)b * C, 0, lp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gradR =
+        __builtin_amdgcn_make_buffer_rsrc(grad_b, 0, lp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsR = __builtin_amdgcn_make_buffer_rsrc(
+        p.alphas + (size_t)b * H, 0, ws_bytes, 0x00020000);
+    const u32 OOB = 0xFFFFFFFFu;
+    auto ld = [&](__amdgpu_buffer_rsrc_t R, u32 off) -> float {
+#ifdef ASR_SL_NOMEM
+        (void)R; return -1.f - 1e-9f * (float)off;
+#else
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R, off, 0, 0));
+#endif
+    };
+    auto st = [&](__amdgpu_buffer_rsrc_t R, u32 off, float v) {
+#ifdef ASR_SL_NOMEM
+        (void)R; if (off == 12345u) red[0] = v;
+#else
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), R, off, 0, 0);
+#endif
+    };
+
+    // ---- arcs of this group in registers --------------------------------
+    const float *s0[K];
+    float r_w[K];
+    {
+        const int Kg = grp ? Kout : Kin;
+        const int32_t *oth = (grp ? p.dst_out : p.src_in) + (size_t)g * N * Kg;
+        const float *wp = (grp ? p.w_out : p.w_in) + (size_t)g * N * Kg;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool v = own && k < Kg;
+            s0[k] = sbuf + (v ? oth[n * Kg + k] : 0);
+            const float w = v ? wp[n * Kg + k] : p.neg_inf;
+            r_w[k] = w > half_inf ? w * ASR_L2E : NI2;
+        }
+    }
+    float *const mine = sbuf + n;
+    const float term2 = own ? fmaxf(term[n], p.neg_inf) * ASR_L2E : NI2;
+    float breg = term2;                               // B: beta_{t+1}[n] (log2)
+    float logZ2 = 0.f;
+    const int lane = threadIdx.x & 63;
+    const int l0 = __builtin_amdgcn_readfirstlane(label);
+    const bool shared_label = label == l0;
+    const bool isB = grp != 0;                        // wave-uniform
+
+    // per-group linear schedules (joint step i = 0..m-1 of each phase):
+    //   phase 0: A frame i,   emission e_i,        store slot i
+    //            B frame tb = len-1-solo-i, emission e_{tb-1}, store slot tb
+    //   phase 1: A frame m+i, emission e_{m+i},    load slot m+i+1, flush frame m+i-1
+    //            B frame m-1-i, emission e_{m-2-i}, load slot m-1-i, flush frame m-i
+    const int dir = isB ? -1 : 1;
+    const u32 estep = (u32)dir * ts4, wstep = (u32)dir * as4;
+    const u32 lab4 = (u32)label * 4u, n4 = (u32)n * 4u;
+    auto eoff = [&](int f) -> u32 { return lab4 + (u32)f * ts4; };
+    auto woff = [&](int slot) -> u32 { return n4 + (u32)slot * as4; };
+    const int fE0 = isB ? len - 2 - solo : 0;
+    const int sS0 = isB ? len - 1 - solo : 0;
+    const int fE1 = isB ? m - 2 : m;
+    const int sL1 = isB ? m - 1 : m + 1;
+    const int fG1 = isB ? m + 1 : m - 2;      // frame of step i-2 at i = 0
+
+    u32 wcur = 0;                     // phase 0: ws store offset of this step
+    u32 gcur = 0;                     // phase 1: grad offset of the row to flush
+    // phase 1 keeps three rotating gradient rows per group: the posteriors of
+    // step i are added to row ra during step i+1 (while that step's LDS reads
+    // are in flight) and the row is streamed out during step i+2.
+    int ra = 0, rf = Cpad, rn = 2 * Cpad;
+    float gprev = 0.f;                // posterior of the previous step, not yet added
+
+    // side work of phase-1 step i: add gprev into row ra, flush row rf
+    // (frame of step i-2, offset gcur, masked off while i < 2), rotate.
+    // ONE unconditional ds_add per lane (exact LDS op count keeps the
+    // compiler's lgkmcnt waits counted): lane 0 adds the DPP-reduced total of
+    // the wave's shared label, lanes with another label add their own
+    // posterior, everything else (zeros) goes to a lane-private sink.
+    // (LDS float adds cost ~4 cycles per ACTIVE lane on gfx950: for small C
+    // only lanes with a non-zero, non-shared posterior issue one; for large C
+    // the single unconditional form is faster — measured 878 -> 783 us on the
+    // bigram numerator — because it keeps the lgkmcnt waits counted.)
+    auto side_accumulate = [&]() {
+        const float tot = dpp_wave_sum(shared_label ? gprev : 0.f);
+        if (FL == 1) {
+            float *rw = row + ra;
+            if (lane == 0 && tot != 0.f) atomicAdd(&rw[l0], tot);
+            if (!shared_label && gprev != 0.f) atomicAdd(&rw[label], gprev);
+        } else {
+            const float v = lane == 0 ? tot : (shared_label ? 0.f : gprev);
+            float *dst = v != 0.f ? row + ra + label : ldump;
+            atomicAdd(dst, v);
+        }
+    };
+    auto side_rotate = [&]() {
+        const int t = rf; rf = ra; ra = rn; rn = t;
+    };
+
+    // one recurrence step, identical instruction stream for both groups.
+    // PH: phase; RD: LDS buffer read (writes RD^1); SOLO: 0 both groups
+    // active, 1 only B, 2 only A (the idle group keeps its state).
+    auto step = [&](auto ph_c, auto rd_c, auto solo_c, float ev, float wv, bool do_flush) {
+        constexpr int PH = decltype(ph_c)::value;
+        constexpr int RD = decltype(rd_c)::value;
+        constexpr int SOLO = decltype(solo_c)::value;
+        const int wr = (RD ^ 1) * H;
+        const bool act = SOLO == 0 ? true : (SOLO == 1 ? isB : !isB);
+        float x[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) x[k] = s0[k][RD * H];
+        float fl = 0.f;
+        const int ci = n < C ? n : 0;
+        if (PH == 1 && FL == 1) fl = row[rf + ci];
+        if (PH == 1) {
+            // keep the LDS reads ahead of the DPP reduction: it runs in their shadow
+            __builtin_amdgcn_sched_barrier(0);
+            side_accumulate();
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) x[k] += r_w[k];
+        float mx = x[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k]);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) sum += __builtin_amdgcn_exp2f(x[k] - mx);
+        float val0 = mx + __builtin_amdgcn_logf(sum);     // B: beta_t
+        float val1 = fmaf(ev, ASR_L2E, val0);             // A: alpha_{t+1}; B: beta_t + lp_{t-1}
+        if (SOLO != 0) {
+            const float keep = mine[RD * H];
+            val1 = act ? val1 : keep;
+        }
+        mine[wr] = val1;
+        if (PH == 0) {
+            st(wsR, (SOLO == 0 || act) ? wcur : OOB, isB ? val0 : val1);
+        } else {
+            if (FL == 1) {
+                const bool v = do_flush && n < C;
+                *(v ? row + rf + ci : ldump) = 0.f;
+                st(gradR, v ? gcur : OOB, fl);
+            }
+            float gam = __builtin_amdgcn_exp2f((isB ? breg : val1) + wv - logZ2);
+            if (!own || !act) gam = 0.f;
+            gprev = gam;
+            if (FL == 1) {
+            } else if (do_flush) {
+                for (int c = n; c < C; c += H) {
+                    st(gradR, gcur + (u32)(c - n) * 4u, row[rf + c]);
+                    row[rf + c] = 0.f;
+                }
+            }
+            side_rotate();
+        }
+        if (SOLO == 0 || act) breg = val0;
+        SL_BARRIER();
+    };
+    // phase-1 drain step: side work only
+    auto drain = [&](bool do_flush) {
+        const int ci = n < C ? n : 0;
+        side_accumulate();
+        gprev = 0.f;
+        if (FL == 1) {
+            const float fl = row[rf + ci];
+            const bool v = do_flush && n < C;
+            *(v ? row + rf + ci : ldump) = 0.f;
+            st(gradR, v ? gcur : OOB, fl);
+        } else if (do_flush) {
+            for (int c = n; c < C; c += H) {
+                st(gradR, gcur + (u32)(c - n) * 4u, row[rf + c]);
+                row[rf + c] = 0.f;
+            }
+        }
+        side_rotate();
+        __syncthreads();
+    };
+    auto copy_back = [&]() {          // buffer 1 -> buffer 0 (restore parity)
+        mine[0] = mine[H];
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+
+    // ---- initial state ----------------------------------------------------
+    {
+        const float e_last = ld(lpR, eoff(len - 1));          // OOB -> 0 when len == 0
+        mine[0] = isB ? (own ? fmaf(e_last, ASR_L2E, term2) : NI2)   // beta_len + lp_{len-1}
+                      : ((n == 0) ? 0.f : NI2);                      // alpha_0
+        st(wsR, isB ? woff(len) : OOB, term2);                // slot len = beta_len
+    }
+    for (int c = n; c < 3 * Cpad; c += H) row[c] = 0.f;
+    __syncthreads();
+
+    float e[D], eh[D], wsr[D], wh[D];
+#ifdef ASR_SL_STAMPS
+    unsigned long long stamp[6];
+#define SL_STAMP(i) stamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define SL_STAMP(i) do {} while (0)
+#endif
+    SL_STAMP(0);
+
+    // ================= phase 0 ============================================
+    if (solo) {                                   // B alone: frame len-1
+        const float ev = ld(lpR, isB ? eoff(len - 2) : OOB);
+        wcur = woff(len - 1);
+        step(I0(), I0(), I1(), ev, 0.f, false);
+        copy_back();
+    }
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        eh[u] = ld(lpR, eoff(fE0 + dir * u));
+        e[u] = ld(lpR, eoff(fE0 + dir * (r + u)));
+    }
+    wcur = woff(sS0);
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (u < r) {
+            if (u & 1) step(I0(), I1(), I0(), eh[u], 0.f, false);
+            else step(I0(), I0(), I0(), eh[u], 0.f, false);
+            wcur += wstep;
+        }
+    if (r & 1) copy_back();
+    {
+        u32 epf = eoff(fE0 + dir * (r + D));      // emission of step i + D
+        for (int c = 0; c < q; ++c) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                if (u & 1) step(I0(), I1(), I0(), e[u], 0.f, false);
+                else step(I0(), I0(), I0(), e[u], 0.f, false);
+                wcur += wstep;
+                e[u] = ld(lpR, epf);
+                epf += estep;
+            }
+        }
+    }
+
+    SL_STAMP(1);
+    // ================= meeting point ======================================
+#pragma unroll
+    for (int u = 0; u < D; ++u) {                 // prime phase-1 rings early
+        eh[u] = ld(lpR, eoff(fE1 + dir * u));
+        e[u] = ld(lpR, eoff(fE1 + dir * (r + u)));
+        wh[u] = ld(wsR, woff(sL1 + dir * u));
+        wsr[u] = ld(wsR, woff(sL1 + dir * (r + u)));
+    }
+    if (isB) mine[H] = breg;                      // pure beta_m in the spare buffer
+    __syncthreads();
+    {
+        const float *al = smem;                   // alpha_m: A buffer 0
+        const float *be = smem + 3 * H;           // beta_m:  B buffer 1
+        float mx = -INFINITY;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) mx = fmaxf(mx, al[i] + be[i]);
+        mx = block_max(mx, red);
+        float sum = 0.f;
+        for (int i = threadIdx.x; i < N; i += blockDim.x)
+            sum += __builtin_amdgcn_exp2f(al[i] + be[i] - mx);
+        sum = block_sum(sum, red);
+        logZ2 = mx + __builtin_amdgcn_logf(sum);
+    }
+    __syncthreads();
+
+    SL_STAMP(2);
+    // ================= phase 1 ============================================
+    const u32 gstep = estep;
+    gcur = n4 + (u32)fG1 * ts4;                   // row flushed at step 0 (masked off)
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (u < r) {
+            if (u & 1) step(I1(), I1(), I0(), eh[u], wh[u], u > 1);
+            else step(I1(), I0(), I0(), eh[u], wh[u], u > 1);
+            gcur += gstep;
+        }
+    if (r & 1) copy_back();
+    {
+        u32 epf = eoff(fE1 + dir * (r + D));
+        u32 wpf = woff(sL1 + dir * (r + D));
+        for (int c = 0; c < q; ++c) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const bool fl = (r + c * D + u) > 1;
+                if (u & 1) step(I1(), I1(), I0(), e[u], wsr[u], fl);
+                else step(I1(), I0(), I0(), e[u], wsr[u], fl);
+                gcur += gstep;
+                e[u] = ld(lpR, epf);
+                wsr[u] = ld(wsR, wpf);
+                epf += estep;
+                wpf += wstep;
+            }
+        }
+    }
+    SL_STAMP(3);
+    if (solo) {                                   // A alone: frame len-1
+        const float ev = ld(lpR, isB ? OOB : eoff(len - 1));
+        const float wv = ld(wsR, isB ? OOB : woff(len));       // beta_len
+        step(I1(), I0(), I2(), ev, wv, m > 1);
+        gcur += gstep;
+    }
+    {   // drain: rows of the last two steps (B's row for A's solo step is
+        // empty and its frame offset is out of range)
+        const int S = m + solo;
+        drain(S > 1);
+        gcur += gstep;
+        drain(S > 0);
+    }
+    {   // logZ = logsumexp_n(alpha_len + terminal) (fst_utils.py:445)
+        const float *al = smem + (solo ? H : 0);
+        float mx = -INFINITY;
+        for (int i = threadIdx.x; i < N; i += blockDim.x)
+            mx = fmaxf(mx, al[i] + fmaxf(term[i], p.neg_inf) * ASR_L2E);
+        mx = block_max(mx, red);
+        float sum = 0.f;
+        for (int i = threadIdx.x; i < N; i += blockDim.x)
+            sum += __builtin_amdgcn_exp2f(al[i] + fmaxf(term[i], p.neg_inf) * ASR_L2E - mx);
+        sum = block_sum(sum, red);
+        if (threadIdx.x == 0) p.logZ[b] = (mx + __builtin_amdgcn_logf(sum)) * ASR_LN2;
+    }
+    // fst_utils.py:476: logsumexp(alpha_0 + beta_0) == beta_0[0]
+    if (p.logZ_bwd && isB && n == 0) p.logZ_bwd[b] = breg * ASR_LN2;
+#ifdef ASR_SL_STAMPS
+    SL_STAMP(4);
+    __syncthreads();
+    if (threadIdx.x == 0 && p.T > 0) {
+        float *o = grad_b + (size_t)(p.T - 1) * tstride;
+        for (int i = 0; i < 4; ++i) o[i] = (float)(stamp[i + 1] - stamp[i]);
+    }
+#endif
+}
+
 struct FwdParams {
     const float *lp;
     int T, B, C;
@@ -355,7 +1054,9 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 extern "C" int64_t asr_lattice_fwbw_workspace_bytes(int T, int B, int C, int N) {
     (void)C;
     if (T < 0 || B < 0 || N < 0) return -1;
-    return (int64_t)T * B * N * (int64_t)sizeof(float) + 256;
+    // [T+2, B, round_up(N,64)] f32 (+1 slot: beta_len, +1: store dump) + flags [B]
+    const int64_t H = (N + 63) / 64 * 64;
+    return (int64_t)(T + 2) * B * H * (int64_t)sizeof(float) + (int64_t)B * 4 + 256;
 }
 
 extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
@@ -388,21 +1089,45 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     p.N = N; p.Kin = Kin; p.Kout = Kout; p.Bg = Bg; p.neg_inf = neg_inf;
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
+    p.flags = nullptr;
 
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
-    const size_t lds = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
-    if (lds > 160 * 1024) return ASR_EUNSUPPORTED;
+    size_t lds = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     const int Kmax = Kin > Kout ? Kin : Kout;
     void (*kern)(FwbwParams);
     int nt;
-    if (N <= 1024 && Kmax <= 4) {
+    const size_t lds_mitm = (size_t)(4 * Npad + 4 * Cpad + 64) * sizeof(float);
+    const bool fits32 = (size_t)T * B * C * 4 < (1ull << 31) &&
+                        (size_t)(T + 2) * B * round_up(N, 64) * 4 < (1ull << 31);
+    if (N <= 512 && Kmax <= 4 && lds_mitm <= 160 * 1024 && fits32) {
+        // fast path for state-labelled graphs first; utterances that fail its
+        // entry check are flagged and picked up by the generic kernel behind.
+        const int H = round_up(N, 64);
+        const size_t lds_sl = (size_t)(4 * H + 6 * Cpad + 64 + 2 * H) * sizeof(float);
+        p.flags = (int32_t *)((char *)workspace + (size_t)(T + 2) * B * H * sizeof(float));
+        void (*fast)(FwbwParams);
+        if (C <= H)
+            fast = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 1> : lattice_fwbw_sl_kernel<4, 8, 1>;
+        else
+            fast = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 0> : lattice_fwbw_sl_kernel<4, 8, 0>;
+        if (lds_sl > 64 * 1024 &&
+            hipFuncSetAttribute((const void *)fast,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_sl) != hipSuccess)
+            return ASR_EUNSUPPORTED;
+        hipLaunchKernelGGL(fast, dim3(B), dim3(2 * H), lds_sl, s, p);
+        kern = lattice_fwbw_mitm_kernel<4, 8>;
+        nt = 2 * H;
+        lds = lds_mitm;
+    } else if (N <= 1024 && Kmax <= 4) {
         kern = lattice_fwbw_kernel<4>;
         nt = round_up(N, 64);
     } else {
         kern = lattice_fwbw_kernel<0>;
         nt = N >= 1024 ? 1024 : round_up(N, 64);
     }
+    if (lds > 160 * 1024) return ASR_EUNSUPPORTED;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)kern,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
