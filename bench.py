@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py — CTC train-step frames/s on MI355X (BASELINE.json metric).
+
+One "step" = forward + backward + Adam of SpeechModel(DeepSpeech2 encoder +
+FSTDecoder, mono-char CTC: egs/wsj/yamls/ctc.yaml shapes) on one synthetic batch
+of B utterances x 1000 fbank frames x 40 dims per GPU; frames/s is the reference's
+own throughput definition, sum(feature_lens) / step_time (trainer.py:292-298).
+N > 1: one process per GPU (torch.distributed.run), utterance-sharded data
+parallelism, one RCCL all-reduce of the flat gradient bucket per step.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement), with
+  roofline     — the lattice forward-backward scan kernel, HBM-bound, timed live
+                 with events on the stream it is launched on;
+  cpu_baseline — the same step on the host cores (torch-CPU encoder + the CPU
+                 oracle for the lattice), bounded sample, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'pytorch-asr_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np                      # noqa: E402
+import torch                            # noqa: E402
+import torch.distributed as dist        # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+S = 49                                  # egs/wsj/vocabulary.txt
+
+
+def model_config(order=1):
+    enc = dict(class_name='att_speech.modules.encoders.DeepSpeech2',
+               conv_kernel_sizes=[[7, 7], [7, 7]], conv_strides=[[1, 2], [3, 1]],
+               rnn_hidden_size=320, rnn_nb_layers=4, rnn_normalization='none')
+    dec = dict(class_name='att_speech.modules.decoders.advanced_decoder.FSTDecoder',
+               denominator_red='none', normalize_by_dim=0,
+               graph_generator=dict(class_name='CTCGraphGen', context_order=order))
+    return enc, dec
+
+
+def synthetic_batch(B, T, rank, order=1):
+    """features N(0,1) [B,T,40,1]; saturating batch = all-T
+    lengths (B > 16), YAML batch = T - 8b; labels uniform in [2,48],
+    L_b = 100 - 2 (b mod 16)."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    feats = torch.randn(B, T, 40, 1, generator=g)
+    lens = torch.tensor([T if B > 16 else T - 8 * b for b in range(B)], dtype=torch.int32)
+    llens = torch.tensor([100 - 2 * (b % 16) for b in range(B)], dtype=torch.int32)
+    texts = torch.randint(2, S, (B, 100), generator=g, dtype=torch.int32)
+    if order == 2:      # bigram ids prev*S+cur (egs/wsj/data.py:146-161)
+        prev = torch.cat([torch.zeros(B, 1, dtype=torch.int32), texts[:, :-1]], 1)
+        texts = prev * S + texts
+    for b in range(B):
+        texts[b, llens[b]:] = 0
+    return feats, lens, texts, llens
+
+
+def lattice_algorithmic_bytes(enc_lens, C, label_lens, n_arcs):
+    """sum_b 4*T'_b*(3C + 2N_b) + 2*E_b*12 + 4*N_b."""
+    tl = np.asarray(enc_lens, np.int64)
+    ns = 2 * np.asarray(label_lens, np.int64) + 1
+    return int((4 * tl * (3 * C + 2 * ns) + 24 * np.asarray(n_arcs, np.int64) + 4 * ns).sum())
+
+
+def cpu_baseline(T, order, seconds_budget=20.0):
+    """The same training step on the host: torch-CPU encoder/projection +
+    oracle/lattice_oracle.c for the lattice (kind 'port'), small batch."""
+    from att_speech.models import SpeechModel
+    from att_speech import fst_utils
+    from oracle import oracle
+
+    class OracleLattice(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, lp, lens, mats):
+            r = oracle.path_logsumexp(lp.detach().numpy(), lens.numpy(),
+                                      [m.numpy() for m in mats])
+            ctx.grads = torch.from_numpy(r['grad'])
+            return torch.from_numpy(r['logZ'])
+
+        @staticmethod
+        def backward(ctx, g):
+            return g[None, :, None] * ctx.grads, None, None
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 4
+    feats, lens, texts, llens = synthetic_batch(B, T, 0, order)
+    enc_cfg, dec_cfg = model_config(order)
+    torch.manual_seed(1234)
+    sb = {'features': feats.clone(), 'features_lengths': lens.clone(), 'spkids': None}
+    model = SpeechModel(enc_cfg, dec_cfg, sb, S ** order, [str(i) for i in range(S)])
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    gg = fst_utils.CTCGraphGen(context_order=order, num_symbols=S)
+
+    def step():
+        opt.zero_grad()
+        enc, elens = model.encoder(feats, lens, None)
+        logits = model.decoder.fc(enc)
+        lp = torch.log_softmax(logits, -1)
+        mx = lp.max(-1, keepdim=True)[0].detach()
+        mask = (torch.arange(lp.size(0))[:, None] < elens[None, :]).float()
+        mats = gg.get_training_matrices_batch(texts, llens)
+        num = -OracleLattice.apply(lp - mx, elens, mats)
+        loss = (num - (mx.squeeze(-1) * mask).sum(0)).sum()
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    step()                                   # warm-up
+    t0, n = time.time(), 0
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 50):
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=float(lens.sum()) / dt, unit='frames/s', cores=cores, kind='port',
+                sample='%d steps of the same train step at B=%d x %d frames on the host '
+                       '(torch-CPU encoder + oracle/lattice_oracle.c lattice, 1 thread)'
+                       % (n, B, T))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=512, help='utterances per GPU')
+    ap.add_argument('--frames', type=int, default=1000)
+    ap.add_argument('--order', type=int, default=1, help='1 mono-char CTC, 2 bi-char CTC')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+
+    from att_speech import _native, fst_utils
+    from att_speech.dp import FlatGradBucket, broadcast_parameters
+    from att_speech.models import SpeechModel
+
+    B, T, order = a.batch, a.frames, a.order
+    C = S ** order
+    feats, lens, texts, llens = synthetic_batch(B, T, rank, order)
+    enc_cfg, dec_cfg = model_config(order)
+    torch.manual_seed(1234)
+    sb = {'features': feats[:2].clone(), 'features_lengths': lens[:2].clone(), 'spkids': None}
+    model = SpeechModel(enc_cfg, dec_cfg, sb, C, [str(i) for i in range(S)]).to(dev)
+    broadcast_parameters(model)
+    bucket = FlatGradBucket(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    feats_d = feats.to(dev)                          # inputs resident in HBM
+    # graph matrices are built per batch on the host like the reference's data
+    # workers do (kaldi_dataset.py:230-232) and handed over with the batch
+    graph_matrices = model.decoder.graph_generator.get_training_matrices_batch(texts, llens)
+    n_arcs = (graph_matrices[2] > -1e19).sum((1, 2)).numpy()
+    enc_lens = ((lens + 2) // 3).numpy()
+
+    lat_events = []
+    _native.EVENT_HOOK = None
+
+    def step(record=False):
+        bucket.zero_()
+        if record:
+            _native.EVENT_HOOK = lat_events
+        out = model(feats_d, lens, None, texts, llens, graph_matrices=graph_matrices)
+        _native.EVENT_HOOK = None
+        out['loss'].backward()
+        bucket.all_reduce_sum()
+        opt.step()
+        return out['loss']
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.time()
+    for _ in range(a.steps):
+        loss = step(record=True)
+    fence()
+    dt = time.time() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    frames = torch.tensor([float(lens.sum())], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(frames, op=dist.ReduceOp.SUM)
+    total_frames = float(frames.item())
+
+    if rank == 0:
+        lat_ms = [s.elapsed_time(e) for (s, e) in lat_events]
+        lat_ms = float(np.mean(lat_ms)) if lat_ms else float('nan')
+        alg = lattice_algorithmic_bytes(enc_lens, C, llens.numpy(), n_arcs)
+        achieved = alg / (lat_ms * 1e-3) / 1e9
+        res = {
+            'metric': 'CTC train-step frames/sec',
+            'value': total_frames * a.steps / dt,
+            'unit': 'frames/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': dt / a.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'WSJ %s-char CTC (egs/wsj/yamls/%s.yaml shapes), DeepSpeech2 '
+                                   'conv+4xBiLSTM-320 encoder + FSTDecoder, fwd+bwd+Adam, '
+                                   'synthetic 40-dim x %d-frame fbank'
+                                   % ('mono' if order == 1 else 'bi',
+                                      'ctc' if order == 1 else 'ctc_bi', T),
+                       'batch_per_gpu': B, 'global_batch': B * world, 'frames': T,
+                       'classes': C, 'parallelism': 'dp%d' % world,
+                       'final_loss': float(loss)},
+            'roofline': {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'algorithmic_bytes_per_launch': alg,
+                         'avg_launch_ms': lat_ms},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(T, order)
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

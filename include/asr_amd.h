@@ -132,6 +132,14 @@ int asr_sub_rowmax_f32(const float *x, int T, int B, int C,
                        const int32_t *lens, float *y, float *row_max,
                        float *max_sum, void *stream);
 
+/*
+ * Index of the first maximum of every row of x [rows, C]: the per-frame
+ * arg-max of CTCDecoderAdvanced.decode (advanced_decoder.py:352,
+ * `torch.max(logits_t, 2)`).  out_idx [rows] i32.
+ */
+int asr_argmax_rows_f32(const float *x, int64_t rows, int C, int32_t *out_idx,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

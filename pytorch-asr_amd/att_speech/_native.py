@@ -19,6 +19,9 @@ ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
 ABI_VERSION = 1
 
 _lib = None
+# bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
+# around every lattice forward-backward call (launched on the current stream)
+EVENT_HOOK = None
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -36,6 +39,7 @@ _SIGNATURES = {
     'asr_log_softmax_fwd_f32': (_i, [_vp, _i64, _i, _vp, _vp]),
     'asr_log_softmax_bwd_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'asr_sub_rowmax_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'asr_argmax_rows_f32': (_i, [_vp, _i64, _i, _vp, _vp]),
 }
 
 
@@ -136,12 +140,20 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
     zb = torch.empty(B, dtype=torch.float32, device=lp.device) if want_bwd_total else None
     nbytes = L.asr_lattice_fwbw_workspace_bytes(T, B, C, graph.N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=lp.device)
+    hook = EVENT_HOOK
+    if hook is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(L.asr_lattice_fwbw_f32(
         _p(lp), T, B, C, _p(lens), _p(graph.src_in), _p(graph.il_in),
         _p(graph.w_in), _p(graph.term), _p(graph.dst_out), _p(graph.il_out),
         _p(graph.w_out), graph.N, graph.Kin, graph.Kout, graph.Bg,
         float(neg_inf), _p(logZ), _p(grad), _p(zb), _p(ws), nbytes, _stream()),
         'asr_lattice_fwbw_f32')
+    if hook is not None:
+        ev1.record()
+        hook.append((ev0, ev1))
     return logZ, grad, zb
 
 
@@ -198,3 +210,13 @@ def sub_rowmax(x, lens):
     check(lib().asr_sub_rowmax_f32(_p(x), T, B, C, _p(lens), _p(y), _p(row_max),
                                    _p(max_sum), _stream()), 'asr_sub_rowmax_f32')
     return y, row_max, max_sum
+
+
+def argmax_rows(x):
+    """asr_argmax_rows_f32 over the last axis: returns int32 indices x.shape[:-1]."""
+    x = _dev(x, torch.float32, 'logits')
+    C = x.shape[-1]
+    out = torch.empty(x.shape[:-1], dtype=torch.int32, device=x.device)
+    check(lib().asr_argmax_rows_f32(_p(x), x.numel() // C, C, _p(out), _stream()),
+          'asr_argmax_rows_f32')
+    return out

@@ -1,0 +1,72 @@
+"""Utterance-sharded data parallelism for the training step (new functionality:
+the reference is single-process).
+
+One process per GPU.  Every rank holds a replica, runs forward/backward on its
+own shard of utterances (each shard re-sorted by length, descending, as the
+lattice scan requires) and the gradients are SUMMED across ranks with one
+all-reduce over a single flat fp32 bucket: the loss is a sum over utterances
+(advanced_decoder.py:524-527), so gradients add — no averaging.  Parameter
+gradients are views into the bucket, so backward writes straight into it and the
+collective needs no packing copy.  Backend: 'nccl' (= RCCL over xGMI on ROCm)
+for GPU tensors, 'gloo' in the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradBucket(object):
+    """All parameter gradients of `params` as views into one flat buffer."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev, dt = self.params[0].device, self.params[0].dtype
+        assert all(p.device == dev and p.dtype == dt for p in self.params)
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        # keeps the views alive (optimizer.zero_grad(set_to_none=True) would drop them)
+        self.flat.zero_()
+
+    def check_views(self):
+        """backward accumulates in place into .grad when it exists; re-attach a
+        view if something replaced it."""
+        off = 0
+        for p in self.params:
+            view = self.flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
+            off += p.numel()
+
+    def all_reduce_sum(self, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            self.check_views()
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+
+def shard_batch(lengths, world_size):
+    """Global batch (indices sorted by length, descending) -> per-rank index
+    lists, dealt in snake order (0..W-1, W-1..0, ...) so every shard has about
+    the same total number of frames and a similar longest utterance; each list
+    stays sorted descending (fst_utils.py:382,432, deep_speech_2.py:152 hold
+    per shard)."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    shards = [[] for _ in range(world_size)]
+    for pos, i in enumerate(order):
+        rnd, k = divmod(pos, world_size)
+        shards[k if rnd % 2 == 0 else world_size - 1 - k].append(i)
+    return shards
+
+
+def broadcast_parameters(module, src=0, group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=group)

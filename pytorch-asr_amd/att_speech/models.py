@@ -1,0 +1,64 @@
+"""reference att_speech/models.py:21-97 — SpeechModel = encoder o decoder."""
+from __future__ import absolute_import, division, print_function
+
+import itertools
+
+import torch
+from torch import nn
+
+from att_speech import utils
+
+
+class SpeechModel(nn.Module):
+    def __init__(self, encoder, decoder, sample_batch, num_classes, vocabulary,
+                 **kwargs):
+        super(SpeechModel, self).__init__(**kwargs)
+        self.encoder = utils.contruct_from_kwargs(
+            encoder, 'att_speech.modules.encoders', {'sample_batch': sample_batch})
+        with torch.no_grad():                       # size probe (:29-30)
+            was_training = self.encoder.training
+            self.encoder.eval()
+            sample_batch["features"], sample_batch["features_lens"] = (
+                self.encoder(**_encoder_kwargs(sample_batch)))
+            self.encoder.train(was_training)
+        self.decoder = utils.contruct_from_kwargs(
+            decoder, 'att_speech.modules.decoders',
+            {'sample_batch': sample_batch, 'num_classes': num_classes,
+             'vocabulary': vocabulary})
+
+    def load_state(self, state_dict, strict=True):
+        self.load_state_dict(state_dict, strict)
+
+    def forward(self, features, feature_lens, spkids, texts, text_lens,
+                ivectors=None, **kwargs):
+        encoded, encoded_lens = self.encoder(features, feature_lens, spkids,
+                                             ivectors, **kwargs)
+        return self.decoder(encoded, encoded_lens, texts, text_lens,
+                            spkids=spkids, **kwargs)
+
+    def decode(self, features, feature_lens, speakers, texts=None,
+               text_lens=None, encoder_args=None, decoder_args=None,
+               ivectors=None, **kwargs):
+        encoder_args = {} if encoder_args is None else encoder_args
+        decoder_args = {} if decoder_args is None else decoder_args
+        encoder_args.update(kwargs)
+        decoder_args.update(kwargs)
+        with torch.no_grad():
+            encoded, encoded_lens = self.encoder(
+                features, feature_lens, speakers, ivectors, **encoder_args)
+            return self.decoder.decode(encoded, encoded_lens, texts, text_lens,
+                                       spkids=speakers, **decoder_args)
+
+    def get_parameters_for_optimizer(self):
+        return itertools.chain(self.encoder.get_parameters_for_optimizer(),
+                               self.decoder.parameters())
+
+
+def _encoder_kwargs(sample_batch):
+    """the reference calls self.encoder(**sample_batch) with keys
+    features / features_lengths / spkids (models.py:29-30)."""
+    kw = dict(sample_batch)
+    if 'features_lengths' not in kw and 'features_lens' in kw:
+        kw['features_lengths'] = kw.pop('features_lens')
+    kw.setdefault('spkids', None)
+    return kw

@@ -1,0 +1,95 @@
+"""reference modules/encoders/deep_speech_2.py:14-160 — conv2d+BN+Hardtanh x2
+then bidirectional recurrent layers with summed directions."""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from att_speech.modules.encoders.base_encoder import BaseEncoder
+from att_speech.modules.encoders.encoder_utils import (
+    BatchRNN, Normalization, SequentialWithOptionalAttributes)
+
+
+class DeepSpeech2(BaseEncoder):
+    def __init__(self, sample_batch, conv_normalization='batch_norm',
+                 conv_strides=[[2, 2], [2, 1]],
+                 conv_kernel_sizes=[[41, 11], [21, 11]],
+                 conv_num_features=[32, 32],
+                 rnn_hidden_size=768, rnn_nb_layers=5, rnn_projection_size=0,
+                 rnn_type=nn.LSTM, rnn_dropout=0.0, rnn_residual=False,
+                 rnn_normalization='batch_norm', rnn_subsample=None, **kwargs):
+        super(DeepSpeech2, self).__init__(**kwargs)
+        if isinstance(rnn_type, str):
+            rnn_type = {'LSTM': nn.LSTM, 'GRU': nn.GRU}[rnn_type.split('.')[-1]]
+        self.makeConv(sample_batch, conv_strides, conv_kernel_sizes,
+                      conv_num_features, conv_normalization)
+        features = sample_batch['features']
+        features = features.permute(0, 3, 1, 2)
+        with torch.no_grad():
+            was_training = self.conv.training
+            self.conv.eval()        # size probe only: do not touch BN statistics
+            after_conv_size = self.conv.forward(features).size()
+            self.conv.train(was_training)
+        self.rnn_input_size = after_conv_size[1] * after_conv_size[3]
+        self.makeRnn(rnn_hidden_size, rnn_nb_layers, rnn_projection_size,
+                     rnn_type, rnn_dropout, rnn_residual, rnn_normalization,
+                     rnn_subsample)
+
+    def makeConv(self, sample_batch, conv_strides, conv_kernel_sizes,
+                 conv_num_features, normalization):
+        num_channels = sample_batch['features'].size()[3]
+        conv_padding = int(0.5 * (
+            conv_kernel_sizes[1][0] - 1 +
+            conv_strides[0][0] * (conv_kernel_sizes[0][0] - 1)))      # (:56-58)
+        self.conv_cumative_stride = conv_strides[0][0] * conv_strides[1][0]
+        self.conv = nn.Sequential(
+            nn.Conv2d(num_channels, conv_num_features[0],
+                      kernel_size=tuple(conv_kernel_sizes[0]),
+                      stride=tuple(conv_strides[0]), padding=(conv_padding, 0)),
+            Normalization(normalization, 2, conv_num_features[0]),
+            nn.Hardtanh(0, 20, inplace=True),
+            nn.Conv2d(conv_num_features[0], conv_num_features[1],
+                      kernel_size=tuple(conv_kernel_sizes[1]),
+                      stride=tuple(conv_strides[1])),
+            Normalization(normalization, 2, conv_num_features[1]),
+            nn.Hardtanh(0, 20, inplace=True))
+
+    def makeRnn(self, rnn_hidden_size, rnn_nb_layers, rnn_projection_size,
+                rnn_type, rnn_dropout, rnn_residual, normalization,
+                rnn_subsample):
+        if rnn_subsample is None:
+            rnn_subsample = []
+        rnn_dropout = nn.Dropout(p=rnn_dropout) if rnn_dropout > 0.0 else None
+        rnns = [('0', BatchRNN(input_size=self.rnn_input_size,
+                               hidden_size=rnn_hidden_size, rnn_type=rnn_type,
+                               bidirectional=True, packed_data=True,
+                               normalization=None,
+                               projection_size=rnn_projection_size,
+                               subsample=(0 in rnn_subsample)))]
+        for i in range(rnn_nb_layers - 1):
+            rnn = BatchRNN(input_size=(rnn_hidden_size if rnn_projection_size == 0
+                                       else rnn_projection_size),
+                           projection_size=rnn_projection_size,
+                           hidden_size=rnn_hidden_size, rnn_type=rnn_type,
+                           bidirectional=True, packed_data=True,
+                           normalization=normalization, residual=rnn_residual,
+                           subsample=(i + 1 in rnn_subsample))
+            if rnn_dropout:
+                rnns.append(('{}_dropout'.format(i + 1), rnn_dropout))
+            rnns.append(('{}'.format(i + 1), rnn))
+        self.rnns = SequentialWithOptionalAttributes(OrderedDict(rnns))
+
+    def forward(self, features, features_lengths, spkids, ivectors=None,
+                characteristic_vectors=None, **kwargs):
+        # bs x t x f x c -> bs x c x t x f
+        features = features.permute(0, 3, 1, 2)
+        features = self.conv(features)
+        batch_size, _, num_timestp, _ = features.size()
+        # bs x c x t x f -> t x bs x (c x f)
+        features = features.permute(2, 0, 1, 3).contiguous()
+        features = features.view(num_timestp, batch_size, -1)
+        features_lengths = torch.as_tensor(features_lengths)
+        features_lengths = ((features_lengths + self.conv_cumative_stride - 1)
+                            // self.conv_cumative_stride).int()          # (:149-151)
+        assert features_lengths[0] == features.size()[0]                 # (:152)
+        return self.rnns(features, features_lengths, spkids)

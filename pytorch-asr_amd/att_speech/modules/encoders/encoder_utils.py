@@ -1,0 +1,120 @@
+"""reference modules/encoders/encoder_utils.py: Normalization (:16-52),
+BatchRNN (:55-124), SequentialWithOptionalAttributes (:127-133).
+
+The recurrent layers work on PADDED [T,B,F] tensors plus lengths instead of
+PackedSequence objects: padding frames are masked inside the recurrence, which
+yields the same values on every valid frame (a packed bidirectional LSTM starts
+its reverse direction at each utterance's own last frame — so does the masked
+one) and lets the input projection run as one dense [T*B, F] GEMM."""
+from __future__ import division, print_function
+
+import inspect
+
+import torch
+from torch import nn
+
+
+class Identity(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super(Identity, self).__init__()
+
+    def forward(self, x):
+        return x
+
+
+class Normalization(nn.Module):
+    def __init__(self, norm_type, nary, input_size):
+        super(Normalization, self).__init__()
+        self.nary = nary
+        if norm_type == 'batch_norm':
+            if nary == 1:
+                self.batch_norm = nn.BatchNorm1d(input_size)
+            elif nary == 2:
+                self.batch_norm = nn.BatchNorm2d(input_size)
+            else:
+                raise ValueError("Unknown nary for {} normalization".format(norm_type))
+        elif norm_type == 'instance_norm':
+            if nary == 1:
+                self.batch_norm = nn.InstanceNorm1d(input_size)
+            elif nary == 2:
+                self.batch_norm = nn.InstanceNorm2d(input_size)
+            else:
+                raise ValueError("Unknown nary for {} normalization".format(norm_type))
+        elif not norm_type or norm_type == 'none':
+            self.batch_norm = Identity()
+        else:
+            raise ValueError(
+                "Unknown normalization type {}. Possible are: batch_norm, "
+                "instance_norm or none".format(norm_type))
+
+    def forward(self, x, speaker=None):
+        return self.batch_norm(x)
+
+
+class BatchRNN(nn.Module):
+    """One (bi)directional recurrent layer, bias-free, directions summed
+    (reference encoder_utils.py:55-124).  `self.rnn` is an nn.LSTM / nn.GRU so
+    the state_dict keys (rnn.weight_ih_l0, rnn.weight_hh_l0, *_reverse) are the
+    reference's; input is (padded [T,B,F], lens [B])."""
+
+    def __init__(self, input_size, hidden_size, rnn_type=nn.LSTM,
+                 bidirectional=False, packed_data=False, normalization=None,
+                 projection_size=0, residual=False, subsample=False):
+        super(BatchRNN, self).__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.bidirectional = bidirectional
+        self.residual = residual
+        self.batch_norm = Normalization(normalization, 1, input_size)
+        self.rnn = rnn_type(input_size=input_size, hidden_size=hidden_size,
+                            bidirectional=bidirectional, bias=False)
+        self.num_directions = 2 if bidirectional else 1
+        self.subsample = subsample
+        if projection_size > 0:
+            self.projection = torch.nn.Linear(
+                hidden_size * self.num_directions, projection_size, bias=False)
+        else:
+            self.projection = None
+
+    def flatten_parameters(self):
+        self.rnn.flatten_parameters()
+
+    def forward(self, x, lens, speakers=None):
+        """x [T,B,F] padded, lens [B] (CPU int, sorted descending)."""
+        T, B, _ = x.shape
+        lens_t = torch.as_tensor(lens)
+        if self.residual:
+            res = x
+        if not isinstance(self.batch_norm.batch_norm, Identity):
+            # the reference normalises the packed data, i.e. valid frames only
+            mask = (torch.arange(T)[:, None] < lens_t[None, :]).to(x.device)
+            flat = x[mask]
+            x = x.clone()
+            x[mask] = self.batch_norm(flat)
+        packed = nn.utils.rnn.pack_padded_sequence(x, lens_t.cpu())
+        y, _ = self.rnn(packed)
+        y, _ = nn.utils.rnn.pad_packed_sequence(y, total_length=T)
+        if self.subsample:
+            y = y[::2]
+            lens_t = lens_t // 2
+        if self.projection is not None:
+            y = self.projection(y)
+        elif self.bidirectional:
+            y = y.view(y.size(0), y.size(1), 2, -1).sum(2)      # (T,B,2H) -> (T,B,H)
+        if self.residual:
+            y = torch.nn.functional.relu(y + res)
+        return y, lens_t
+
+
+class SequentialWithOptionalAttributes(nn.Sequential):
+    """reference :127-133 (py3: inspect instead of func_code); modules that
+    take (x, lens, ...) return (x, lens)."""
+
+    def forward(self, input, lens, *args):
+        for module in self._modules.values():
+            if isinstance(module, BatchRNN):
+                nparams = len(inspect.signature(module.forward).parameters)
+                input, lens = module(input, lens, *args[:max(0, nparams - 2)])
+            else:
+                input = module(input)
+        return input, lens

@@ -123,6 +123,34 @@ __global__ void max_sum_kernel(const float *__restrict__ row_max,
     if (lane == 0) max_sum[b] = s;
 }
 
+// first maximum of every row (one wave per row): CTCDecoderAdvanced.decode's
+// per-frame arg-max (advanced_decoder.py:352).
+template <int PER>
+__global__ void argmax_rows_kernel(const float *__restrict__ x,
+                                   int32_t *__restrict__ out, int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float *xr = x + r * C;
+        float best = -INFINITY;
+        int arg = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int c = i * 64 + lane;
+            float v = c < C ? xr[c] : -INFINITY;
+            if (c < C && (v > best || arg == 0x7fffffff)) { best = v; arg = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o, 64);
+            int oa = __shfl_xor(arg, o, 64);
+            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+        if (lane == 0) out[r] = arg;
+    }
+}
+
 inline int grid_for(int64_t rows) {
     int64_t blocks = (rows + 3) / 4;       // 4 waves (rows) per 256-thread block
     if (blocks > 8192) blocks = 8192;
@@ -185,5 +213,17 @@ extern "C" int asr_sub_rowmax_f32(const float *x, int T, int B, int C,
 #undef CALL
     }
     hipLaunchKernelGGL(max_sum_kernel, dim3(B), dim3(64), 0, s, row_max, lens, max_sum, T, B);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_argmax_rows_f32(const float *x, int64_t rows, int C,
+                                   int32_t *out_idx, void *stream) {
+    if (rows < 0 || C <= 0) return ASR_EINVAL;
+    if (rows == 0) return ASR_OK;
+    if (!x || !out_idx) return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(P) hipLaunchKernelGGL(argmax_rows_kernel<P>, dim3(grid_for(rows)), dim3(256), 0, s, x, out_idx, rows, C)
+    DISPATCH_PER(C, CALL);
+#undef CALL
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
