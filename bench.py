@@ -67,7 +67,7 @@ def lattice_algorithmic_bytes(enc_lens, C, label_lens, n_arcs):
     return int((4 * tl * (3 * C + 2 * ns) + 24 * np.asarray(n_arcs, np.int64) + 4 * ns).sum())
 
 
-def cpu_baseline(T, order, seconds_budget=20.0):
+def cpu_baseline(T, order, seconds_budget=15.0):
     """The same training step on the host: torch-CPU encoder/projection +
     oracle/lattice_oracle.c for the lattice (kind 'port'), small batch."""
     from att_speech.models import SpeechModel
@@ -86,7 +86,13 @@ def cpu_baseline(T, order, seconds_budget=20.0):
         def backward(ctx, g):
             return g[None, :, None] * ctx.grads, None, None
 
-    cores = os.cpu_count() or 1
+    # the box's CPU share for one GPU is 16 cores; os.cpu_count() reports the
+    # whole host and oversubscribing it is pathologically slow
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     B = 4
     feats, lens, texts, llens = synthetic_batch(B, T, 0, order)
@@ -128,7 +134,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=512, help='utterances per GPU')
+    ap.add_argument('--batch', type=int, default=128, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--order', type=int, default=1, help='1 mono-char CTC, 2 bi-char CTC')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -185,8 +191,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    t_start = time.time()
+
+    def progress(msg):
+        if rank == 0:
+            print('[bench %6.1fs] %s' % (time.time() - t_start, msg), file=sys.stderr, flush=True)
+
+    for i in range(a.warmup):
         step()
+        torch.cuda.synchronize()
+        progress('warmup step %d done' % i)
     fence()
     t0 = time.time()
     for _ in range(a.steps):
@@ -230,6 +244,7 @@ def main():
                          'avg_launch_ms': lat_ms},
         }
         if world == 1 and not a.no_cpu_baseline:
+            progress('timing the CPU baseline (about 20 s)')
             res['cpu_baseline'] = cpu_baseline(T, order)
         else:
             res['cpu_baseline'] = None

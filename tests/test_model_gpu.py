@@ -79,8 +79,11 @@ def test_speech_model_train_step_matches_cpu(oracle_lib, cfg):
     feats, lens, texts, llens = make_batch(B, T, S, L, order, 11)
     sb = sample_batch(B=2, T=T)
     model = SpeechModel(ENC, dec_cfg, sb, S ** order, vocab)
-    model.eval()                   # BN in eval mode: batch statistics are not
-    ref = copy.deepcopy(model)     # part of the lattice parity question
+    model.train()
+    for mod in model.modules():    # BN in eval mode: batch statistics are not
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):   # part of the parity question
+            mod.eval()
+    ref = copy.deepcopy(model)
     want, want_g = cpu_reference_loss(ref, feats, lens, texts, llens, oracle_lib,
                                       order, denominator=(cfg != 'mono_ctc'))
     model.to(dev())
@@ -92,7 +95,9 @@ def test_speech_model_train_step_matches_cpu(oracle_lib, cfg):
     for k, p in model.named_parameters():
         g, w = p.grad.cpu(), want_g[k]
         scale = max(float(w.abs().max()), 1e-3)
-        assert float((g - w).abs().max()) <= 2e-3 * scale, k
+        # relative to the tensor's largest gradient, plus an absolute floor for
+        # gradients that cancel analytically (e.g. a global bias under CTC-G)
+        assert float((g - w).abs().max()) <= 2e-3 * scale + 1e-5, k
     # graph matrices handed over by the data pipeline (first-batch self check,
     # advanced_decoder.py:460-468) give the same loss
     gm = model.decoder.graph_generator.get_training_matrices_batch(texts, llens)
@@ -146,7 +151,7 @@ def test_ctc_decoder_advanced_matches_torch_ctc():
     # greedy decode: per-frame arg-max, bug-compatible collapse
     with torch.no_grad():
         res = dec.decode(enc.to(dev()), elens)
-        logits = ref.logits(enc)
+        logits = torch.log_softmax(ref.fc(enc), -1)
     frames = logits.argmax(-1).transpose(0, 1)
     np.testing.assert_array_equal(res['decoded_frames'].numpy(), frames.numpy())
     assert res['decoded'] == ref.process_sequences(frames, elens)
