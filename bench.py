@@ -134,7 +134,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=128, help='utterances per GPU')
+    ap.add_argument('--batch', type=int, default=512, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--order', type=int, default=1, help='1 mono-char CTC, 2 bi-char CTC')
     ap.add_argument('--no-cpu-baseline', action='store_true')

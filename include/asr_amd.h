@@ -140,6 +140,42 @@ int asr_sub_rowmax_f32(const float *x, int T, int B, int C,
 int asr_argmax_rows_f32(const float *x, int64_t rows, int C, int32_t *out_idx,
                         void *stream);
 
+/*
+ * Bidirectional, bias-free LSTM recurrence on a padded, length-masked batch —
+ * the sequential part of BatchRNN (modules/encoders/encoder_utils.py:55-124:
+ * nn.LSTM(bidirectional=True, bias=False) applied to a PackedSequence).
+ * The caller supplies the input projection of every frame,
+ *   gx [T,B,2,4H] f32 = x · W_ihᵀ   (direction-major, gate order i,f,g,o),
+ * and the recurrent weights as bf16 (MFMA operands; accumulation, gates and
+ * the cell state are fp32):  whh [2,4H,H] for the forward pass,
+ * whhT [2,H,4H] (transposed) for the backward pass.
+ * Utterance b is active at frame t iff t < lens[b]; padding frames emit zeros
+ * and carry no gradient, which reproduces pack_padded_sequence semantics
+ * (the reverse direction starts at each utterance's own last frame).
+ *   y      [T,B,2,H]   per-direction hidden outputs (the reference sums the
+ *                      two directions, encoder_utils.py:112-117)
+ *   gates  [T,2,B,4,H] post-activation gates, csave [T,2,B,H] cell states:
+ *                      saved by the forward pass for the backward pass
+ *   dy     [T,B,2,H]   gradient w.r.t. y
+ *   dgates [T,B,2,4H]  gradient w.r.t. the gate pre-activations (= w.r.t. gx);
+ *                      the caller forms dx, dW_ih, dW_hh from it with dense GEMMs
+ * workspace: asr_lstm_workspace_bytes(B, H) bytes.  H must be a multiple of 32.
+ */
+int64_t asr_lstm_workspace_bytes(int B, int H);
+
+int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
+                            const int32_t *lens, int T, int B, int H,
+                            float *y, float *gates, float *csave,
+                            void *workspace, int64_t workspace_bytes,
+                            void *stream);
+
+int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
+                            const int32_t *lens, int T, int B, int H,
+                            const float *gates, const float *csave,
+                            float *dgates,
+                            void *workspace, int64_t workspace_bytes,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

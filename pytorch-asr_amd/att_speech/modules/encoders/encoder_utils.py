@@ -79,6 +79,11 @@ class BatchRNN(nn.Module):
     def flatten_parameters(self):
         self.rnn.flatten_parameters()
 
+    def _use_native(self, x):
+        # the MI355X path: hand-written recurrence kernels (csrc/lstm.hip)
+        return (x.is_cuda and isinstance(self.rnn, nn.LSTM) and self.bidirectional
+                and self.hidden_size % 32 == 0 and not self.rnn.bias)
+
     def forward(self, x, lens, speakers=None):
         """x [T,B,F] padded, lens [B] (CPU int, sorted descending)."""
         T, B, _ = x.shape
@@ -91,9 +96,15 @@ class BatchRNN(nn.Module):
             flat = x[mask]
             x = x.clone()
             x[mask] = self.batch_norm(flat)
-        packed = nn.utils.rnn.pack_padded_sequence(x, lens_t.cpu())
-        y, _ = self.rnn(packed)
-        y, _ = nn.utils.rnn.pad_packed_sequence(y, total_length=T)
+        if self._use_native(x):
+            from att_speech.modules.encoders.native_lstm import bilstm
+            y = bilstm(x, lens_t, self.rnn).view(T, B, -1)      # [T,B,2H], zeros on padding
+        else:
+            # host / non-LSTM evaluation with stock torch ops (CPU reference in
+            # the tests and bench.py's cpu_baseline; GRU layers)
+            packed = nn.utils.rnn.pack_padded_sequence(x, lens_t.cpu())
+            y, _ = self.rnn(packed)
+            y, _ = nn.utils.rnn.pad_packed_sequence(y, total_length=T)
         if self.subsample:
             y = y[::2]
             lens_t = lens_t // 2
