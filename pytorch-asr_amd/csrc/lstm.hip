@@ -14,6 +14,15 @@
 // direction and stays L2-resident across the steps), then the four gate tiles
 // meet in LDS for the pointwise cell update in fp32.
 //
+// MFMA operand layout: both GEMM operands live in memory in FRAGMENT-MAJOR
+// order — for a [32 rows x K] tile, k-step ks is the 1 KiB block
+// [64 lanes][8 bf16] with lane l = (row & 31) + 32*((k>>3)&1) — so a wave's
+// fragment load is one fully coalesced 1 KiB access (a row-major tile makes
+// every load touch 32 cache lines and the address coalescer, not the MFMA,
+// sets the pace: measured 9k cycles just to ISSUE the 40 loads).  The h /
+// dgates ping-pong buffers are written in that order by the pointwise phase;
+// W_hh is re-packed once per call by lstm_pack_kernel.
+//
 // Packed-sequence semantics with a padded batch: utterance b is active at
 // frame t iff t < lens[b]; inactive frames keep (h, c) and emit zeros, so the
 // reverse direction starts from the zero state at each utterance's own last
@@ -35,10 +44,10 @@ __device__ __forceinline__ float tanhf_(float x) {
 
 struct LstmFwdParams {
     const float *gx;        // [T,B,2,4H] x·W_ihᵀ, gate order i,f,g,o
-    const __bf16 *whh;      // [2,4H,H]
+    const __bf16 *whh;      // fragment-major pack of [2*4 (dir,gate)][H rows][H cols]
     const int32_t *lens;    // [B]
     int T, B, H;
-    __bf16 *hbuf;           // [2 pingpong][2 dir][B][H]
+    __bf16 *hbuf;           // [2 pingpong][2 dir] fragment-major [Bp x H], Bp = B padded to 32
     float *cbuf;            // [2 dir][B][H]
     float *y;               // [T,B,2,H] per-direction outputs (zeros when inactive)
     float *gates;           // [T,2,B,4,H] post-activation gates (saved for backward)
@@ -46,32 +55,117 @@ struct LstmFwdParams {
     int step;
 };
 
+// K-loop of one wave: acc += A[32 x 16*KS] * B[16*KS x 32] with both operands
+// read from global memory (L2) in MFMA fragment order.  With KS known at
+// compile time the loop is fully unrolled and every fragment load is issued
+// before the first MFMA, so the L2 latency is paid once, not per k-step.
+// element (row b, column k) of a [rows x 16*KS] operand in fragment-major order
+__device__ __forceinline__ size_t frag_off(int b, int k, int KS) {
+    return ((((size_t)(b >> 5) * KS + (k >> 4)) * 64 + ((b & 31) + 32 * ((k >> 3) & 1))) << 3) + (k & 7);
+}
+
+// out = fragment-major copy of `rows` x `cols` (cols % 16 == 0, rows % 32 == 0)
+// row-major bf16 matrices, `nmat` of them; transpose != 0 reads in[c][r].
+__global__ void lstm_pack_kernel(const __bf16 *in, __bf16 *out, int nmat, int rows,
+                                 int cols, int transpose) {
+    const size_t per = (size_t)rows * cols;
+    const size_t total = per * nmat;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / per);
+        const size_t rem = i % per;
+        const int r = (int)(rem / cols), c = (int)(rem % cols);
+        const __bf16 v = transpose ? in[(size_t)m * per + (size_t)c * rows + r]
+                                   : in[(size_t)m * per + rem];
+        out[(size_t)m * per + frag_off(r, c, cols / 16)] = v;
+    }
+}
+
+template <int KS>
+struct Frags {
+    bf16x8 a[KS > 0 ? KS : 1], b[KS > 0 ? KS : 1];
+    __device__ __forceinline__ void load(const __bf16 *ap, const __bf16 *bp) {
+        if constexpr (KS > 0) {
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                a[k] = *reinterpret_cast<const bf16x8 *>(ap + k * 512);
+                b[k] = *reinterpret_cast<const bf16x8 *>(bp + k * 512);
+            }
+        }
+    }
+};
+
+template <int KS>
+__device__ __forceinline__ f32x16 mfma_rows(const Frags<KS> &fr, const __bf16 *ap,
+                                            const __bf16 *bp, int H) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if constexpr (KS > 0) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.a[k], fr.b[k], acc, 0, 0, 0);
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < H / 16; ++k) {
+            const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(ap + k * 512);
+            const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(bp + k * 512);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
 // grid: x = hidden tile (H/32), y = batch tile (ceil(B/32)), z = direction
+#ifdef ASR_LSTM_STAMPS
+#define STAMP(i) stamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+template <int KS>
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
+#ifdef ASR_LSTM_STAMPS
+    unsigned long long stamp[4];
+    const unsigned long long stamp_start = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ float g_lds[4][32][33];
     const int H = p.H, B = p.B;
     const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32, dir = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = dir == 0 ? p.step : p.T - 1 - p.step;
-    const __bf16 *hprev = p.hbuf + ((size_t)(p.step & 1) * 2 + dir) * B * H;
-    __bf16 *hnext = p.hbuf + ((size_t)((p.step + 1) & 1) * 2 + dir) * B * H;
+    const int Bp = (B + 31) & ~31, KSr = H / 16;
+    const __bf16 *hprev = p.hbuf + ((size_t)(p.step & 1) * 2 + dir) * Bp * H;
+    __bf16 *hnext = p.hbuf + ((size_t)((p.step + 1) & 1) * 2 + dir) * Bp * H;
+
+    // ---- MFMA fragments first: vmcnt retires in order, so the (L2-resident)
+    // fragment loads must not queue behind the HBM loads of the pointwise phase
+    const __bf16 *fr_ap = hprev + ((size_t)blockIdx.y * KSr * 64 + lane) * 8;
+    const __bf16 *fr_bp = p.whh + ((size_t)(dir * 4 + wave) * H * H) +
+                          ((size_t)blockIdx.x * KSr * 64 + lane) * 8;
+    Frags<KS> fr;
+    fr.load(fr_ap, fr_bp);
+    STAMP(0);
+
+    // ---- operands of the pointwise phase: issued now, consumed after the GEMM
+    float pgx[4][4], pc[4];
+    bool pact[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = e * 256 + threadIdx.x;
+        const int b = b0 + (idx >> 5), j = j0 + (idx & 31);
+        const int bc = b < B ? b : B - 1;
+        pact[e] = b < B && t < p.lens[bc];
+        const float *gxp = p.gx + (((size_t)t * B + bc) * 2 + dir) * 4 * H + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pgx[e][g] = gxp[g * H];
+        pc[e] = p.cbuf[((size_t)dir * B + bc) * H + j];
+    }
 
     // ---- gate pre-activation tile: [32 batch] x [32 hidden of gate `wave`]
     {
-        const int r = lane & 31, kh = (lane >> 5) * 8;
-        int brow = b0 + r;
-        if (brow >= B) brow = B - 1;                    // clamp (masked at the store)
-        const __bf16 *ap = hprev + (size_t)brow * H + kh;
-        const __bf16 *bp = p.whh + ((size_t)dir * 4 * H + (size_t)wave * H + j0 + r) * H + kh;
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < H; k += 16) {
-            const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(ap + k);
-            const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(bp + k);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
-        }
+        const f32x16 acc = mfma_rows<KS>(fr, fr_ap, fr_bp, H);
+        STAMP(1);
         const int col = lane & 31;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -80,6 +174,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
         }
     }
     __syncthreads();
+    STAMP(2);
 
     // ---- pointwise cell update: 1024 (b, j) elements over 256 threads
 #pragma unroll
@@ -88,21 +183,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
         const int row = idx >> 5, col = idx & 31;
         const int b = b0 + row, j = j0 + col;
         if (b < B) {
-        const bool active = t < p.lens[b];
+        const bool active = pact[e];
         const size_t sidx = ((size_t)dir * B + b) * H + j;
         float *yo = p.y + (((size_t)t * B + b) * 2 + dir) * H + j;
         const size_t gsave = ((((size_t)t * 2 + dir) * B + b) * 4) * H + j;
         const size_t csv = (((size_t)t * 2 + dir) * B + b) * H + j;
         if (active) {
-            const float *gxp = p.gx + (((size_t)t * B + b) * 2 + dir) * 4 * H + j;
-            const float gi = sigmoidf_(g_lds[0][row][col] + gxp[0]);
-            const float gf = sigmoidf_(g_lds[1][row][col] + gxp[H]);
-            const float gg = tanhf_(g_lds[2][row][col] + gxp[2 * H]);
-            const float go = sigmoidf_(g_lds[3][row][col] + gxp[3 * H]);
-            const float c = gf * p.cbuf[sidx] + gi * gg;
+            const float gi = sigmoidf_(g_lds[0][row][col] + pgx[e][0]);
+            const float gf = sigmoidf_(g_lds[1][row][col] + pgx[e][1]);
+            const float gg = tanhf_(g_lds[2][row][col] + pgx[e][2]);
+            const float go = sigmoidf_(g_lds[3][row][col] + pgx[e][3]);
+            const float c = gf * pc[e] + gi * gg;
             const float h = go * tanhf_(c);
             p.cbuf[sidx] = c;
-            hnext[(size_t)b * H + j] = (__bf16)h;
+            hnext[frag_off(b, j, KSr)] = (__bf16)h;
             *yo = h;
             p.gates[gsave] = gi;
             p.gates[gsave + H] = gf;
@@ -110,27 +204,37 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
             p.gates[gsave + 3 * H] = go;
             p.csave[csv] = c;
         } else {
-            hnext[(size_t)b * H + j] = hprev[(size_t)b * H + j];
+            hnext[frag_off(b, j, KSr)] = hprev[frag_off(b, j, KSr)];
             *yo = 0.f;
-            p.csave[csv] = p.cbuf[sidx];
+            p.csave[csv] = pc[e];
         }
         }
     }
+    STAMP(3);
+#ifdef ASR_LSTM_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0 && b0 < B) {
+        float *o = p.y + (((size_t)t * B + b0) * 2 + dir) * H + j0;
+        o[0] = (float)(stamp[0] - stamp_start);
+        for (int i = 1; i < 4; ++i) o[i] = (float)(stamp[i] - stamp[i - 1]);
+    }
+#endif
 }
 
 struct LstmBwdParams {
     const float *dy;        // [T,B,2,H] gradient w.r.t. the per-direction outputs
-    const __bf16 *whhT;     // [2,H,4H]  (W_hh transposed: k-contiguous for dgates·W_hh)
+    const __bf16 *whhT;     // fragment-major pack of W_hhᵀ: [2 dir][H rows][4H cols]
     const int32_t *lens;
     int T, B, H;
     const float *gates;     // [T,2,B,4,H]
     const float *csave;     // [T,2,B,H]
-    __bf16 *dgbuf;          // [2 pingpong][2 dir][B][4H] dgates of the previous step
+    __bf16 *dgbuf;          // [2 pingpong][2 dir] fragment-major [Bp x 4H]: dgates of the previous step
     float *dcbuf;           // [2 dir][B][H] carried dL/dc
     float *dgates;          // [T,B,2,4H] pre-activation gate gradients (output)
     int step;
 };
 
+template <int KS>
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
     __shared__ float part[4][32][33];
     const int H = p.H, B = p.B, H4 = 4 * p.H;
@@ -138,26 +242,43 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // the backward scan visits frames in the opposite order of the forward one
     const int t = dir == 0 ? p.T - 1 - p.step : p.step;
-    const __bf16 *dgprev = p.dgbuf + ((size_t)(p.step & 1) * 2 + dir) * B * H4;
-    __bf16 *dgnext = p.dgbuf + ((size_t)((p.step + 1) & 1) * 2 + dir) * B * H4;
+    const int Bp = (B + 31) & ~31, KSr = H / 16, KS4 = H4 / 16;
+    const __bf16 *dgprev = p.dgbuf + ((size_t)(p.step & 1) * 2 + dir) * Bp * H4;
+    __bf16 *dgnext = p.dgbuf + ((size_t)((p.step + 1) & 1) * 2 + dir) * Bp * H4;
+
+    // wave w covers k-steps [w*KSr, (w+1)*KSr) of K = 4H (the columns of gate w)
+    const __bf16 *fr_ap = dgprev + (((size_t)blockIdx.y * KS4 + (size_t)wave * KSr) * 64 + lane) * 8;
+    const __bf16 *fr_bp = p.whhT + (size_t)dir * H * H4 +
+                          (((size_t)blockIdx.x * KS4 + (size_t)wave * KSr) * 64 + lane) * 8;
+    Frags<KS> fr;
+    fr.load(fr_ap, fr_bp);
+
+    // ---- operands of the pointwise phase: issued now, consumed after the GEMM
+    float pg[4][4], pcs[4], pcp[4], pdy[4], pdc[4];
+    bool pact[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = e * 256 + threadIdx.x;
+        const int b = b0 + (idx >> 5), j = j0 + (idx & 31);
+        const int bc = b < B ? b : B - 1;
+        const int len = p.lens[bc];
+        pact[e] = b < B && t < len;
+        const size_t gsave = ((((size_t)t * 2 + dir) * B + bc) * 4) * H + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pg[e][g] = p.gates[gsave + g * H];
+        pcs[e] = p.csave[(((size_t)t * 2 + dir) * B + bc) * H + j];
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        const int tpc = tp < 0 ? 0 : (tp >= p.T ? p.T - 1 : tp);
+        const float cpv = p.csave[(((size_t)tpc * 2 + dir) * B + bc) * H + j];
+        pcp[e] = (tp >= 0 && tp < len) ? cpv : 0.f;
+        pdy[e] = p.dy[(((size_t)t * B + bc) * 2 + dir) * H + j];
+        pdc[e] = p.dcbuf[((size_t)dir * B + bc) * H + j];
+    }
 
     // ---- dh_rec[b][j] = sum_k dgates_prev[b][k] * W_hh[k][j]; K = 4H split
     // over the four waves (wave w takes the columns of gate w)
     {
-        const int r = lane & 31, kh = (lane >> 5) * 8;
-        int brow = b0 + r;
-        if (brow >= B) brow = B - 1;
-        const __bf16 *ap = dgprev + (size_t)brow * H4 + (size_t)wave * H + kh;
-        const __bf16 *bp = p.whhT + ((size_t)dir * H + j0 + r) * H4 + (size_t)wave * H + kh;
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < H; k += 16) {
-            const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(ap + k);
-            const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(bp + k);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
-        }
+        const f32x16 acc = mfma_rows<KS>(fr, fr_ap, fr_bp, H);
         const int col = lane & 31;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -173,41 +294,36 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
         const int row = idx >> 5, col = idx & 31;
         const int b = b0 + row, j = j0 + col;
         if (b < B) {
-        const int len = p.lens[b];
-        const bool active = t < len;
+        const bool active = pact[e];
         const size_t sidx = ((size_t)dir * B + b) * H + j;
         float *dgo = p.dgates + (((size_t)t * B + b) * 2 + dir) * H4 + j;
-        __bf16 *dgn = dgnext + (size_t)b * H4 + j;
         if (active) {
-            const float dh = p.dy[(((size_t)t * B + b) * 2 + dir) * H + j] +
-                             (part[0][row][col] + part[1][row][col]) +
+            const float dh = pdy[e] + (part[0][row][col] + part[1][row][col]) +
                              (part[2][row][col] + part[3][row][col]);
-            const size_t gsave = ((((size_t)t * 2 + dir) * B + b) * 4) * H + j;
-            const float gi = p.gates[gsave], gf = p.gates[gsave + H];
-            const float gg = p.gates[gsave + 2 * H], go = p.gates[gsave + 3 * H];
-            const float c = p.csave[(((size_t)t * 2 + dir) * B + b) * H + j];
-            // cell state the step started from
-            const int tp = dir == 0 ? t - 1 : t + 1;
-            float cprev = 0.f;
-            if (tp >= 0 && tp < len)
-                cprev = p.csave[(((size_t)tp * 2 + dir) * B + b) * H + j];
+            const float gi = pg[e][0], gf = pg[e][1], gg = pg[e][2], go = pg[e][3];
+            const float c = pcs[e];
+            const float cprev = pcp[e];               // cell state the step started from
             const float tc = tanhf_(c);
-            const float dc = dh * go * (1.f - tc * tc) + p.dcbuf[sidx];
+            const float dc = dh * go * (1.f - tc * tc) + pdc[e];
             const float d_o = dh * tc * go * (1.f - go);
             const float d_i = dc * gg * gi * (1.f - gi);
             const float d_f = dc * cprev * gf * (1.f - gf);
             const float d_g = dc * gi * (1.f - gg * gg);
             p.dcbuf[sidx] = dc * gf;
             dgo[0] = d_i; dgo[H] = d_f; dgo[2 * H] = d_g; dgo[3 * H] = d_o;
-            dgn[0] = (__bf16)d_i; dgn[H] = (__bf16)d_f;
-            dgn[2 * H] = (__bf16)d_g; dgn[3 * H] = (__bf16)d_o;
+            dgnext[frag_off(b, j, KS4)] = (__bf16)d_i;
+            dgnext[frag_off(b, H + j, KS4)] = (__bf16)d_f;
+            dgnext[frag_off(b, 2 * H + j, KS4)] = (__bf16)d_g;
+            dgnext[frag_off(b, 3 * H + j, KS4)] = (__bf16)d_o;
         } else {
             // no gradient reaches a padding frame; the carried state gradient
             // restarts from zero (forward: beyond the end; reverse: before the start)
             p.dcbuf[sidx] = 0.f;
             dgo[0] = 0.f; dgo[H] = 0.f; dgo[2 * H] = 0.f; dgo[3 * H] = 0.f;
-            dgn[0] = (__bf16)0.f; dgn[H] = (__bf16)0.f;
-            dgn[2 * H] = (__bf16)0.f; dgn[3 * H] = (__bf16)0.f;
+            dgnext[frag_off(b, j, KS4)] = (__bf16)0.f;
+            dgnext[frag_off(b, H + j, KS4)] = (__bf16)0.f;
+            dgnext[frag_off(b, 2 * H + j, KS4)] = (__bf16)0.f;
+            dgnext[frag_off(b, 3 * H + j, KS4)] = (__bf16)0.f;
         }
         }
     }
@@ -231,9 +347,11 @@ inline void zero_async(void *p, size_t bytes, hipStream_t s) {
 
 extern "C" int64_t asr_lstm_workspace_bytes(int B, int H) {
     if (B < 0 || H < 0) return -1;
-    // forward: hbuf bf16 [2][2][B][H] + cbuf f32 [2][B][H]
-    // backward: dgbuf bf16 [2][2][B][4H] + dcbuf f32 [2][B][H]   (the larger one)
-    return (int64_t)2 * 2 * B * 4 * H * 2 + (int64_t)2 * B * H * 4 + 256;
+    // forward: hbuf bf16 [2][2][Bp][H] + cbuf f32 [2][B][H] + packed W_hh
+    // backward: dgbuf bf16 [2][2][Bp][4H] + dcbuf f32 [2][B][H] + packed W_hhᵀ (larger)
+    const int64_t Bp = (B + 31) / 32 * 32;
+    return (int64_t)2 * 2 * Bp * 4 * H * 2 + (int64_t)2 * B * H * 4 +
+           (int64_t)2 * 4 * H * H * 2 + 256;
 }
 
 extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
@@ -247,16 +365,23 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmFwdParams p;
-    p.gx = gx; p.whh = (const __bf16 *)whh_bf16; p.lens = lens;
+    const size_t Bp = (size_t)(B + 31) / 32 * 32;
+    const size_t hbytes = (size_t)2 * 2 * Bp * H * 2, cbytes = (size_t)2 * B * H * 4;
+    __bf16 *wpack = (__bf16 *)((char *)workspace + hbytes + cbytes);
+    p.gx = gx; p.whh = wpack; p.lens = lens;
     p.T = T; p.B = B; p.H = H;
     p.hbuf = (__bf16 *)workspace;
-    p.cbuf = (float *)((char *)workspace + (size_t)2 * 2 * B * H * 2);
+    p.cbuf = (float *)((char *)workspace + hbytes);
     p.y = y; p.gates = gates; p.csave = csave;
-    zero_async(workspace, (size_t)2 * 2 * B * H * 2 + (size_t)2 * B * H * 4, s);
+    zero_async(workspace, hbytes + cbytes, s);
+    // [2 dir x 4 gates] matrices of H x H (rows = hidden unit, cols = k)
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
+                       (const __bf16 *)whh_bf16, wpack, 8, H, H, 0);
     const dim3 grid(H / 32, (B + 31) / 32, 2);
     for (int step = 0; step < T; ++step) {
         p.step = step;
-        hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(256), 0, s, p);
+        if (H == 320) hipLaunchKernelGGL(lstm_fwd_step_kernel<20>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(lstm_fwd_step_kernel<0>, grid, dim3(256), 0, s, p);
     }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
@@ -274,17 +399,24 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmBwdParams p;
-    p.dy = dy; p.whhT = (const __bf16 *)whhT_bf16; p.lens = lens;
+    const size_t Bp = (size_t)(B + 31) / 32 * 32;
+    const size_t dbytes = (size_t)2 * 2 * Bp * 4 * H * 2, cbytes = (size_t)2 * B * H * 4;
+    __bf16 *wpack = (__bf16 *)((char *)workspace + dbytes + cbytes);
+    p.dy = dy; p.whhT = wpack; p.lens = lens;
     p.T = T; p.B = B; p.H = H;
     p.gates = gates; p.csave = csave;
     p.dgbuf = (__bf16 *)workspace;
-    p.dcbuf = (float *)((char *)workspace + (size_t)2 * 2 * B * 4 * H * 2);
+    p.dcbuf = (float *)((char *)workspace + dbytes);
     p.dgates = dgates;
-    zero_async(workspace, (size_t)2 * 2 * B * 4 * H * 2 + (size_t)2 * B * H * 4, s);
+    zero_async(workspace, dbytes + cbytes, s);
+    // whhT_bf16 is [2][H][4H] row-major: rows = hidden unit j, cols = k over 4H
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
+                       (const __bf16 *)whhT_bf16, wpack, 2, H, 4 * H, 0);
     const dim3 grid(H / 32, (B + 31) / 32, 2);
     for (int step = 0; step < T; ++step) {
         p.step = step;
-        hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, s, p);
+        if (H == 320) hipLaunchKernelGGL(lstm_bwd_step_kernel<20>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(lstm_bwd_step_kernel<0>, grid, dim3(256), 0, s, p);
     }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
