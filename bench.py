@@ -228,7 +228,7 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'WSJ %s-char CTC (egs/wsj/yamls/%s.yaml shapes), DeepSpeech2 '
                                    'conv+4xBiLSTM-320 encoder + FSTDecoder, fwd+bwd+Adam, '
                                    'synthetic 40-dim x %d-frame fbank'

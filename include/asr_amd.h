@@ -154,25 +154,30 @@ int asr_argmax_rows_f32(const float *x, int64_t rows, int C, int32_t *out_idx,
  * (the reverse direction starts at each utterance's own last frame).
  *   y      [T,B,2,H]   per-direction hidden outputs (the reference sums the
  *                      two directions, encoder_utils.py:112-117)
+ *   y_bf16 [2,T+2,B,H] bf16 copy, direction-major, frame t at index t+1 with a
+ *                      zero frame at both ends: h_{t-1} of the forward
+ *                      direction is the slice [0][0:T], of the reverse
+ *                      direction [1][2:T+2] — contiguous GEMM operands for dW_hh
  *   gates  [T,2,B,4,H] post-activation gates, csave [T,2,B,H] cell states:
  *                      saved by the forward pass for the backward pass
  *   dy     [T,B,2,H]   gradient w.r.t. y
- *   dgates [T,B,2,4H]  gradient w.r.t. the gate pre-activations (= w.r.t. gx);
- *                      the caller forms dx, dW_ih, dW_hh from it with dense GEMMs
+ *   dgates_bf16 [T,B,2,4H] bf16: gradient w.r.t. the gate pre-activations
+ *                      (= w.r.t. gx); the caller forms dx, dW_ih, dW_hh from it
+ *                      with dense GEMMs (bf16 operands, fp32 accumulation)
  * workspace: asr_lstm_workspace_bytes(B, H) bytes.  H must be a multiple of 32.
  */
 int64_t asr_lstm_workspace_bytes(int B, int H);
 
 int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
                             const int32_t *lens, int T, int B, int H,
-                            float *y, float *gates, float *csave,
+                            float *y, void *y_bf16, float *gates, float *csave,
                             void *workspace, int64_t workspace_bytes,
                             void *stream);
 
 int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
                             const int32_t *lens, int T, int B, int H,
                             const float *gates, const float *csave,
-                            float *dgates,
+                            void *dgates_bf16,
                             void *workspace, int64_t workspace_bytes,
                             void *stream);
 

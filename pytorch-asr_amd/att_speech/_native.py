@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -41,7 +41,7 @@ _SIGNATURES = {
     'asr_sub_rowmax_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_argmax_rows_f32': (_i, [_vp, _i64, _i, _vp, _vp]),
     'asr_lstm_workspace_bytes': (_i64, [_i, _i]),
-    'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
 
@@ -227,7 +227,7 @@ def argmax_rows(x):
 
 def lstm_bidir_fwd(gx, whh_bf16, lens):
     """asr_lstm_bidir_fwd_bf16: gx [T,B,2,4H] f32, whh [2,4H,H] bf16, lens [B] i32
-    -> (y [T,B,2,H], gates [T,2,B,4,H], csave [T,2,B,H])."""
+    -> (y [T,B,2,H] f32, y_bf16 [2,T+2,B,H], gates [T,2,B,4,H], csave [T,2,B,H])."""
     gx = _dev(gx, torch.float32, 'gx')
     whh_bf16 = _dev(whh_bf16, torch.bfloat16, 'whh')
     lens = _dev(lens, torch.int32, 'lens')
@@ -235,24 +235,25 @@ def lstm_bidir_fwd(gx, whh_bf16, lens):
     H = H4 // 4
     L = lib()
     y = torch.empty((T, B, 2, H), dtype=torch.float32, device=gx.device)
+    ybf = torch.empty((2, T + 2, B, H), dtype=torch.bfloat16, device=gx.device)
     gates = torch.empty((T, 2, B, 4, H), dtype=torch.float32, device=gx.device)
     csave = torch.empty((T, 2, B, H), dtype=torch.float32, device=gx.device)
     nbytes = L.asr_lstm_workspace_bytes(B, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=gx.device)
     check(L.asr_lstm_bidir_fwd_bf16(_p(gx), _p(whh_bf16), _p(lens), T, B, H, _p(y),
-                                    _p(gates), _p(csave), _p(ws), nbytes, _stream()),
-          'asr_lstm_bidir_fwd_bf16')
-    return y, gates, csave
+                                    _p(ybf), _p(gates), _p(csave), _p(ws), nbytes,
+                                    _stream()), 'asr_lstm_bidir_fwd_bf16')
+    return y, ybf, gates, csave
 
 
 def lstm_bidir_bwd(dy, whhT_bf16, lens, gates, csave):
-    """asr_lstm_bidir_bwd_bf16 -> dgates [T,B,2,4H] f32."""
+    """asr_lstm_bidir_bwd_bf16 -> dgates [T,B,2,4H] bf16."""
     dy = _dev(dy, torch.float32, 'dy')
     whhT_bf16 = _dev(whhT_bf16, torch.bfloat16, 'whhT')
     lens = _dev(lens, torch.int32, 'lens')
     T, B, _, H = dy.shape
     L = lib()
-    dgates = torch.empty((T, B, 2, 4 * H), dtype=torch.float32, device=dy.device)
+    dgates = torch.empty((T, B, 2, 4 * H), dtype=torch.bfloat16, device=dy.device)
     nbytes = L.asr_lstm_workspace_bytes(B, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     check(L.asr_lstm_bidir_bwd_bf16(_p(dy), _p(whhT_bf16), _p(lens), T, B, H, _p(gates),

@@ -31,28 +31,27 @@ class BiLSTMFunction(torch.autograd.Function):
         w_ih = torch.cat([w_ih_f, w_ih_r], 0).to(torch.bfloat16)        # [2*4H, F]
         gx = _mm_f32(xb, w_ih.t()).view(T, B, 2, 4 * H)
         whh = torch.stack([w_hh_f, w_hh_r], 0).to(torch.bfloat16).contiguous()
-        y, gates, csave = _native.lstm_bidir_fwd(gx, whh, lens_dev)
-        ctx.save_for_backward(xb, lens_dev, w_ih, whh, y, gates, csave)
+        y, ybf, gates, csave = _native.lstm_bidir_fwd(gx, whh, lens_dev)
+        ctx.save_for_backward(xb, lens_dev, w_ih, whh, ybf, gates, csave)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xb, lens_dev, w_ih, whh, y, gates, csave = ctx.saved_tensors
-        T, B, _, H = y.shape
+        xb, lens_dev, w_ih, whh, ybf, gates, csave = ctx.saved_tensors
+        _, T2, B, H = ybf.shape
+        T = T2 - 2
         F = xb.shape[1]
         whhT = whh.transpose(1, 2).contiguous()                          # [2,H,4H]
-        dgates = _native.lstm_bidir_bwd(dy.contiguous(), whhT, lens_dev, gates, csave)
-        dgb = dgates.view(T * B, 2 * 4 * H).to(torch.bfloat16)
-        dx = _mm_f32(dgb, w_ih).view(T, B, F)
-        dw_ih = _mm_f32(dgb.t(), xb)                                     # [2*4H, F]
-        # h_{t-1}: forward direction looks one frame back, reverse one frame ahead
-        hprev = torch.zeros_like(y)
-        hprev[1:, :, 0] = y[:-1, :, 0]
-        hprev[:-1, :, 1] = y[1:, :, 1]
-        hb = hprev.to(torch.bfloat16)
-        dg = dgb.view(T * B, 2, 4 * H)
-        dw_hh_f = _mm_f32(dg[:, 0].t(), hb[:, :, 0].reshape(T * B, H))
-        dw_hh_r = _mm_f32(dg[:, 1].t(), hb[:, :, 1].reshape(T * B, H))
+        dgb = _native.lstm_bidir_bwd(dy.contiguous(), whhT, lens_dev, gates, csave)
+        dg2 = dgb.view(T * B, 2 * 4 * H)                                 # bf16
+        dx = _mm_f32(dg2, w_ih).view(T, B, F)
+        dw_ih = _mm_f32(dg2.t(), xb)                                     # [2*4H, F]
+        # h_{t-1}: forward direction looks one frame back, reverse one frame
+        # ahead — contiguous slices of the zero-padded bf16 copy
+        hp_f = ybf[0, 0:T].reshape(T * B, H)
+        hp_r = ybf[1, 2:T + 2].reshape(T * B, H)
+        dw_hh_f = _mm_f32(dg2[:, :4 * H].t(), hp_f)
+        dw_hh_r = _mm_f32(dg2[:, 4 * H:].t(), hp_r)
         return dx, None, dw_ih[:4 * H], dw_hh_f, dw_ih[4 * H:], dw_hh_r
 
 

@@ -28,7 +28,6 @@ struct FwbwParams {
     float neg_inf;
     float *logZ, *grad, *logZ_bwd;
     float *alphas;  // [T,B,N]
-    int32_t *flags; // [B] 1 = utterance left to the generic kernel (may be null)
 };
 
 // KR > 0: every thread owns ONE state (N <= blockDim) and keeps its <= KR
@@ -265,10 +264,8 @@ __global__ void lattice_fwbw_kernel(FwbwParams p) {
 #define WS_LOAD(t) ws_b[(size_t)(t) * astride + n]
 #endif
 template <int KR, int D>
-__global__ __launch_bounds__(1024) void lattice_fwbw_mitm_kernel(FwbwParams p) {
-    extern __shared__ float smem[];
+__device__ __forceinline__ void lattice_fwbw_mitm_body(const FwbwParams &p, float *smem) {
     const int b = blockIdx.x;
-    if (p.flags && p.flags[b] == 0) return;          // done by the fast path
     const int H = blockDim.x >> 1;
     const int grp = threadIdx.x >= H ? 1 : 0;        // wave-uniform (H % 64 == 0)
     const int n = threadIdx.x - grp * H;
@@ -486,12 +483,18 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_mitm_kernel(FwbwParams p) {
     }
 }
 
+template <int KR, int D>
+__global__ __launch_bounds__(1024) void lattice_fwbw_mitm_kernel(FwbwParams p) {
+    extern __shared__ float smem[];
+    lattice_fwbw_mitm_body<KR, D>(p, smem);
+}
+
 // ---------------------------------------------------------------------------
 // Fast path for STATE-LABELLED graphs: every valid in-arc of a state carries
 // the same input label.  True for all CTC lattices of the reference (a state
 // of compose(decoding_fst, chain) is "the last emitted class", fst_utils.py:
-// 679-835) and checked per utterance at kernel entry; a graph that fails the
-// check sets flags[b] = 1 and is left to the generic kernel launched behind.
+// 679-835) and checked per utterance at kernel entry; a workgroup whose graph
+// fails the check runs the generic per-arc-label body instead (same launch).
 //
 // With one label per state
 //   alpha_{t+1}[n] = lp_t[label n] + LSE_k(w_k + alpha_t[src_k])
@@ -571,10 +574,9 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
             if (w_in[n * Kin + k] > half_inf && il_in[n * Kin + k] != label) ok = false;
     }
     if (!__syncthreads_and(ok)) {
-        if (threadIdx.x == 0) p.flags[b] = 1;
+        lattice_fwbw_mitm_body<4, 8>(p, smem);
         return;
     }
-    if (threadIdx.x == 0) p.flags[b] = 0;
 
     int len = p.lens[b];
     len = len < 0 ? 0 : (len > p.T ? p.T : len);
@@ -1054,7 +1056,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 extern "C" int64_t asr_lattice_fwbw_workspace_bytes(int T, int B, int C, int N) {
     (void)C;
     if (T < 0 || B < 0 || N < 0) return -1;
-    // [T+2, B, round_up(N,64)] f32 (+1 slot: beta_len, +1: store dump) + flags [B]
+    // [T+2, B, round_up(N,64)] f32 (+1 slot: beta_len, +1: spare)
     const int64_t H = (N + 63) / 64 * 64;
     return (int64_t)(T + 2) * B * H * (int64_t)sizeof(float) + (int64_t)B * 4 + 256;
 }
@@ -1089,7 +1091,6 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     p.N = N; p.Kin = Kin; p.Kout = Kout; p.Bg = Bg; p.neg_inf = neg_inf;
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
-    p.flags = nullptr;
 
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
@@ -1101,25 +1102,16 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     const bool fits32 = (size_t)T * B * C * 4 < (1ull << 31) &&
                         (size_t)(T + 2) * B * round_up(N, 64) * 4 < (1ull << 31);
     if (N <= 512 && Kmax <= 4 && lds_mitm <= 160 * 1024 && fits32) {
-        // fast path for state-labelled graphs first; utterances that fail its
-        // entry check are flagged and picked up by the generic kernel behind.
+        // state-labelled fast path; a workgroup whose graph fails the entry
+        // check runs the generic body inside the same launch
         const int H = round_up(N, 64);
         const size_t lds_sl = (size_t)(4 * H + 6 * Cpad + 64 + 2 * H) * sizeof(float);
-        p.flags = (int32_t *)((char *)workspace + (size_t)(T + 2) * B * H * sizeof(float));
-        void (*fast)(FwbwParams);
         if (C <= H)
-            fast = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 1> : lattice_fwbw_sl_kernel<4, 8, 1>;
+            kern = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 1> : lattice_fwbw_sl_kernel<4, 8, 1>;
         else
-            fast = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 0> : lattice_fwbw_sl_kernel<4, 8, 0>;
-        if (lds_sl > 64 * 1024 &&
-            hipFuncSetAttribute((const void *)fast,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_sl) != hipSuccess)
-            return ASR_EUNSUPPORTED;
-        hipLaunchKernelGGL(fast, dim3(B), dim3(2 * H), lds_sl, s, p);
-        kern = lattice_fwbw_mitm_kernel<4, 8>;
+            kern = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 0> : lattice_fwbw_sl_kernel<4, 8, 0>;
         nt = 2 * H;
-        lds = lds_mitm;
+        lds = lds_sl > lds_mitm ? lds_sl : lds_mitm;
     } else if (N <= 1024 && Kmax <= 4) {
         kern = lattice_fwbw_kernel<4>;
         nt = round_up(N, 64);

@@ -50,6 +50,7 @@ struct LstmFwdParams {
     __bf16 *hbuf;           // [2 pingpong][2 dir] fragment-major [Bp x H], Bp = B padded to 32
     float *cbuf;            // [2 dir][B][H]
     float *y;               // [T,B,2,H] per-direction outputs (zeros when inactive)
+    __bf16 *ybf;            // [2,T+2,B,H] bf16 copy, frame t at index t+1 (zero frames at both ends)
     float *gates;           // [T,2,B,4,H] post-activation gates (saved for backward)
     float *csave;           // [T,2,B,H] cell state after the step
     int step;
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
         const bool active = pact[e];
         const size_t sidx = ((size_t)dir * B + b) * H + j;
         float *yo = p.y + (((size_t)t * B + b) * 2 + dir) * H + j;
+        __bf16 *ybo = p.ybf + (((size_t)dir * (p.T + 2) + t + 1) * B + b) * H + j;
         const size_t gsave = ((((size_t)t * 2 + dir) * B + b) * 4) * H + j;
         const size_t csv = (((size_t)t * 2 + dir) * B + b) * H + j;
         if (active) {
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
             p.cbuf[sidx] = c;
             hnext[frag_off(b, j, KSr)] = (__bf16)h;
             *yo = h;
+            *ybo = (__bf16)h;
             p.gates[gsave] = gi;
             p.gates[gsave + H] = gf;
             p.gates[gsave + 2 * H] = gg;
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
         } else {
             hnext[frag_off(b, j, KSr)] = hprev[frag_off(b, j, KSr)];
             *yo = 0.f;
+            *ybo = (__bf16)0.f;
             p.csave[csv] = pc[e];
         }
         }
@@ -230,7 +234,7 @@ struct LstmBwdParams {
     const float *csave;     // [T,2,B,H]
     __bf16 *dgbuf;          // [2 pingpong][2 dir] fragment-major [Bp x 4H]: dgates of the previous step
     float *dcbuf;           // [2 dir][B][H] carried dL/dc
-    float *dgates;          // [T,B,2,4H] pre-activation gate gradients (output)
+    __bf16 *dgates;         // [T,B,2,4H] pre-activation gate gradients (output, bf16: GEMM operand)
     int step;
 };
 
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
         if (b < B) {
         const bool active = pact[e];
         const size_t sidx = ((size_t)dir * B + b) * H + j;
-        float *dgo = p.dgates + (((size_t)t * B + b) * 2 + dir) * H4 + j;
+        __bf16 *dgo = p.dgates + (((size_t)t * B + b) * 2 + dir) * H4 + j;
         if (active) {
             const float dh = pdy[e] + (part[0][row][col] + part[1][row][col]) +
                              (part[2][row][col] + part[3][row][col]);
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
             const float d_f = dc * cprev * gf * (1.f - gf);
             const float d_g = dc * gi * (1.f - gg * gg);
             p.dcbuf[sidx] = dc * gf;
-            dgo[0] = d_i; dgo[H] = d_f; dgo[2 * H] = d_g; dgo[3 * H] = d_o;
+            dgo[0] = (__bf16)d_i; dgo[H] = (__bf16)d_f; dgo[2 * H] = (__bf16)d_g; dgo[3 * H] = (__bf16)d_o;
             dgnext[frag_off(b, j, KS4)] = (__bf16)d_i;
             dgnext[frag_off(b, H + j, KS4)] = (__bf16)d_f;
             dgnext[frag_off(b, 2 * H + j, KS4)] = (__bf16)d_g;
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
             // no gradient reaches a padding frame; the carried state gradient
             // restarts from zero (forward: beyond the end; reverse: before the start)
             p.dcbuf[sidx] = 0.f;
-            dgo[0] = 0.f; dgo[H] = 0.f; dgo[2 * H] = 0.f; dgo[3 * H] = 0.f;
+            dgo[0] = (__bf16)0.f; dgo[H] = (__bf16)0.f; dgo[2 * H] = (__bf16)0.f; dgo[3 * H] = (__bf16)0.f;
             dgnext[frag_off(b, j, KS4)] = (__bf16)0.f;
             dgnext[frag_off(b, H + j, KS4)] = (__bf16)0.f;
             dgnext[frag_off(b, 2 * H + j, KS4)] = (__bf16)0.f;
@@ -356,12 +360,14 @@ extern "C" int64_t asr_lstm_workspace_bytes(int B, int H) {
 
 extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
                                        const int32_t *lens, int T, int B, int H,
-                                       float *y, float *gates, float *csave,
+                                       float *y, void *y_bf16, float *gates,
+                                       float *csave,
                                        void *workspace, int64_t workspace_bytes,
                                        void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0) return ASR_EINVAL;
     if (T == 0) return ASR_OK;
-    if (!gx || !whh_bf16 || !lens || !y || !gates || !csave || !workspace) return ASR_EINVAL;
+    if (!gx || !whh_bf16 || !lens || !y || !y_bf16 || !gates || !csave || !workspace)
+        return ASR_EINVAL;
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmFwdParams p;
@@ -372,8 +378,13 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
     p.T = T; p.B = B; p.H = H;
     p.hbuf = (__bf16 *)workspace;
     p.cbuf = (float *)((char *)workspace + hbytes);
-    p.y = y; p.gates = gates; p.csave = csave;
+    p.y = y; p.ybf = (__bf16 *)y_bf16; p.gates = gates; p.csave = csave;
     zero_async(workspace, hbytes + cbytes, s);
+    // the two pad frames of every direction of y_bf16
+    for (int d = 0; d < 2; ++d) {
+        zero_async(p.ybf + (size_t)d * (T + 2) * B * H, (size_t)B * H * 2, s);
+        zero_async(p.ybf + ((size_t)d * (T + 2) + T + 1) * B * H, (size_t)B * H * 2, s);
+    }
     // [2 dir x 4 gates] matrices of H x H (rows = hidden unit, cols = k)
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
                        (const __bf16 *)whh_bf16, wpack, 8, H, H, 0);
@@ -389,12 +400,12 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
 extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
                                        const int32_t *lens, int T, int B, int H,
                                        const float *gates, const float *csave,
-                                       float *dgates,
+                                       void *dgates_bf16,
                                        void *workspace, int64_t workspace_bytes,
                                        void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0) return ASR_EINVAL;
     if (T == 0) return ASR_OK;
-    if (!dy || !whhT_bf16 || !lens || !gates || !csave || !dgates || !workspace)
+    if (!dy || !whhT_bf16 || !lens || !gates || !csave || !dgates_bf16 || !workspace)
         return ASR_EINVAL;
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -407,7 +418,7 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
     p.gates = gates; p.csave = csave;
     p.dgbuf = (__bf16 *)workspace;
     p.dcbuf = (float *)((char *)workspace + dbytes);
-    p.dgates = dgates;
+    p.dgates = (__bf16 *)dgates_bf16;
     zero_async(workspace, dbytes + cbytes, s);
     // whhT_bf16 is [2][H][4H] row-major: rows = hidden unit j, cols = k over 4H
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,

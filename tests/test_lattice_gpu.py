@@ -134,6 +134,47 @@ def test_seeded_vs_oracle(oracle_lib, name, kw):
     np.testing.assert_array_equal(best, vil)            # bit-exact, incl. padding rows
 
 
+def test_generic_graph_with_per_arc_labels(oracle_lib):
+    """A graph that is NOT state-labelled (in-arcs of a state carry different
+    input labels) takes the generic body of the same launch; mixed batches
+    (some utterances state-labelled, some not) are handled per workgroup."""
+    from att_speech import fst_utils as P
+    rng = np.random.default_rng(21)
+    C, T, B, N = 11, 45, 4, 37
+    per_utt = []
+    for b in range(B):
+        src, dst, il = [], [], []
+        for n in range(N):
+            for k in range(3):                       # <= 3 in-arcs per state
+                s_ = int(rng.integers(max(0, n - 4), n + 1))
+                if (s_, n) in zip(src, dst):
+                    continue
+                src.append(s_); dst.append(n)
+                # utterance 0 stays state-labelled, the others do not
+                il.append(n % C if b == 0 else int(rng.integers(0, C)))
+        # at most 4 out-arcs per state (drop the excess)
+        keep, outdeg = [], {}
+        for i, s_ in enumerate(src):
+            if outdeg.get(s_, 0) < 4:
+                outdeg[s_] = outdeg.get(s_, 0) + 1
+                keep.append(i)
+        src, dst, il = [np.array(x)[keep] for x in (src, dst, il)]
+        fin = np.full(N, -1e20, np.float32)
+        fin[-3:] = 0.0
+        per_utt.append(P.arcs_to_graph_matrices(
+            N, src, dst, il, rng.uniform(-1, 0, len(src)).astype(np.float32), fin))
+    mats = [m.numpy() for m in P.batch_training_graph_matrices(per_utt)]
+    assert mats[0].shape[2] <= 4 and mats[4].shape[2] <= 4
+    lp = torch.log_softmax(torch.from_numpy(
+        rng.standard_normal((T, B, C)).astype(np.float32)), -1).numpy()
+    lens = np.array([45, 40, 31, 8], np.int32)
+    want = oracle_lib.path_logsumexp(lp, lens, mats)
+    logZ, grad, zb = run_fwbw(lp, lens, mats, want_bwd=True)
+    np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
+    np.testing.assert_allclose(grad, want['grad'], atol=grad_atol(want['logZ']))
+    np.testing.assert_allclose(zb, want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
+
+
 def test_full_size_properties():
     """BASELINE shape (T'=334, C=49, L<=100) at a saturating batch: properties
     that need no oracle — per-frame posteriors sum to one, zero rows past the
