@@ -39,3 +39,18 @@ def edit_distance(x, y):
             cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (xi != yj)))
         prev = cur
     return prev[-1]
+
+
+def get_mask(lengths, mask_length=None, batch_first=True):
+    """1 inside each sequence, 0 on padding (reference utils.py:436-448);
+    always on the CPU like `lengths`."""
+    import torch
+    lengths = torch.as_tensor(lengths)
+    if mask_length is None:
+        mask_length = int(lengths.max())
+    lengths = lengths.long()
+    if batch_first:
+        mask = torch.arange(mask_length) < lengths[:, None]
+    else:
+        mask = torch.arange(mask_length)[:, None] < lengths
+    return mask.float()

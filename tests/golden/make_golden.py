@@ -270,6 +270,63 @@ def golden_embedders_and_greedy():
     save('embedders_greedy.npz', **out)
 
 
+def golden_tcn_beam():
+    """TCN attention decoder + plain BeamSearch (tcn.py:33-585,
+    beam_search.py:13-182).  beam_search.py does not import under py3 (py2
+    `print` statements at :350,:595 — an ordinary SyntaxError), so the
+    `BeamSearch` class is executed from the first 182 lines of the file and
+    handed to the reference's tcn.py through a shim module; tcn.py itself is
+    then imported unchanged."""
+    import warnings
+    warnings.filterwarnings('ignore')
+    from att_speech.configuration import Globals
+    Globals.cuda = False
+    src = open(os.path.join(REF, 'att_speech/modules/beam_search.py')).read().split('\n')
+    ns = {}
+    exec(compile('\n'.join(src[:182]), 'beam_search.py[:182]', 'exec'), ns)
+    shim = types.ModuleType('att_speech.modules.beam_search')
+    shim.BeamSearch = ns['BeamSearch']
+    shim.BeamSearchLM = shim.GraphSearch = shim.RescoreSearchLM = object
+    sys.modules['att_speech.modules.beam_search'] = shim
+    from att_speech.modules import tcn as ref_tcn
+
+    torch.manual_seed(1010)
+    E, Hh, A, S, T, B, L = 16, 24, 8, 7, 14, 3, 5
+    kw = dict(tcn_hidden_size=Hh, att_hidden_size=A, dropout_p=0.0, kernel_size=3,
+              dilation_sizes=[1, 2], beam_size=3, length_normalization=0.6,
+              attention_temperature=1.25, tcn_layers_per_block=2)
+    dec = ref_tcn.AttentionDecoderTCN({'features': torch.zeros(T, B, E)}, S, **kw)
+    dec.eval()
+    with torch.no_grad():
+        for prm in dec.parameters():            # make the decoder non-trivial
+            prm.add_(torch.randn_like(prm) * 0.1)
+        dec.output_to_logits.bias[S] += 2.5      # EOS competitive -> hypotheses finish
+    enc = torch.randn(T, B, E)
+    lens = torch.tensor([14, 11, 8])
+    texts = torch.randint(1, S, (B, L), dtype=torch.int32)
+    tl = torch.tensor([5, 4, 2])
+    out = {'S': np.int32(S), 'enc': enc.numpy(), 'lens': lens.numpy(),
+           'texts': texts.numpy(), 'text_lens': tl.numpy()}
+    for k2, v in dec.state_dict().items():
+        out['sd_' + k2] = v.detach().numpy()
+    fw = dec(enc, lens, texts.clone(), tl, return_att_weights=True)
+    out['fwd_loss'] = fw['loss'].detach().numpy()
+    out['fwd_logits'] = fw['logits'].detach().numpy()
+    out['fwd_att'] = torch.stack(fw['attweights']).detach().numpy()
+    dec.TRANSCRIPTION_LEN_GUARD = 12
+    with torch.no_grad():
+        res = dec.decode(enc, lens, return_attention=True)
+    out['dec_flat'] = np.array([int(c) for d in res['decoded'] for c in
+                                (d.tolist() if hasattr(d, 'tolist') else d)], np.int64)
+    out['dec_lens'] = np.array([len(d) for d in res['decoded']], np.int64)
+    out['dec_scores'] = np.array(res['decoded_scores']['acoustic'], np.float64)
+    out['dec_step_logits'] = torch.cat(res['logits']).numpy()
+    out['dec_final_estimations'] = res['beam_search'].estimations.numpy()
+    out['dec_final_beam_scores'] = res['beam_search'].scores.numpy()
+    out['dec_finished_count'] = np.array(res['beam_search'].finished_count, np.int64)
+    save('tcn_beam.npz', **out)
+
+
 if __name__ == '__main__':
     golden_lattice_mono()
     golden_lattice_bigram()
@@ -277,3 +334,4 @@ if __name__ == '__main__':
     golden_denominator()
     golden_normalized_acts()
     golden_embedders_and_greedy()
+    golden_tcn_beam()
