@@ -21,6 +21,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# pinned MIOpen solver choice for the conv layers that still go through torch
+# (see pytorch-asr_amd/miopen_db/README.md); must be set before MIOpen loads
+os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(ROOT, 'pytorch-asr_amd', 'miopen_db'))
 for p in (ROOT, os.path.join(ROOT, 'pytorch-asr_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)

@@ -164,7 +164,8 @@ int asr_argmax_rows_f32(const float *x, int64_t rows, int C, int32_t *out_idx,
  *   dgates_bf16 [T,B,2,4H] bf16: gradient w.r.t. the gate pre-activations
  *                      (= w.r.t. gx); the caller forms dx, dW_ih, dW_hh from it
  *                      with dense GEMMs (bf16 operands, fp32 accumulation)
- * workspace: asr_lstm_workspace_bytes(B, H) bytes.  H must be a multiple of 32.
+ * workspace: asr_lstm_workspace_bytes(B, H) bytes.  Hidden sizes built:
+ * 64, 128, 256, 320, 384, 512, 768 (ASR_EUNSUPPORTED otherwise).
  */
 int64_t asr_lstm_workspace_bytes(int B, int H);
 

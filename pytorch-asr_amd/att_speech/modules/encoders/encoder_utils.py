@@ -82,7 +82,8 @@ class BatchRNN(nn.Module):
     def _use_native(self, x):
         # the MI355X path: hand-written recurrence kernels (csrc/lstm.hip)
         return (x.is_cuda and isinstance(self.rnn, nn.LSTM) and self.bidirectional
-                and self.hidden_size % 32 == 0 and not self.rnn.bias)
+                and self.hidden_size in (64, 128, 256, 320, 384, 512, 768)
+                and not self.rnn.bias)
 
     def forward(self, x, lens, speakers=None):
         """x [T,B,F] padded, lens [B] (CPU int, sorted descending)."""

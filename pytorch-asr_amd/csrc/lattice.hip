@@ -657,8 +657,12 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
     const int dir = isB ? -1 : 1;
     const u32 estep = (u32)dir * ts4, wstep = (u32)dir * as4;
     const u32 lab4 = (u32)label * 4u, n4 = (u32)n * 4u;
+    // workspace offsets of padding lanes (n >= N) start at 2^31: every buffer
+    // is < 2^31 bytes (host check), so they stay out of range for any slot and
+    // the padded columns cost no HBM traffic
+    const u32 wn4 = own ? n4 : 0x80000000u;
     auto eoff = [&](int f) -> u32 { return lab4 + (u32)f * ts4; };
-    auto woff = [&](int slot) -> u32 { return n4 + (u32)slot * as4; };
+    auto woff = [&](int slot) -> u32 { return wn4 + (u32)slot * as4; };
     const int fE0 = isB ? len - 2 - solo : 0;
     const int sS0 = isB ? len - 1 - solo : 0;
     const int fE1 = isB ? m - 2 : m;
@@ -1100,7 +1104,7 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     int nt;
     const size_t lds_mitm = (size_t)(4 * Npad + 4 * Cpad + 64) * sizeof(float);
     const bool fits32 = (size_t)T * B * C * 4 < (1ull << 31) &&
-                        (size_t)(T + 2) * B * round_up(N, 64) * 4 < (1ull << 31);
+                        (size_t)(T + 2) * B * round_up(N, 64) * 4 < (1ull << 30);
     if (N <= 512 && Kmax <= 4 && lds_mitm <= 160 * 1024 && fits32) {
         // state-labelled fast path; a workgroup whose graph fails the entry
         // check runs the generic body inside the same launch

@@ -35,11 +35,13 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 forms (about 1 ulp each): four instructions per
+// sigmoid instead of a full-precision division sequence
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float tanhf_(float x) {
-    const float e = __expf(-2.f * fabsf(x));
-    const float t = (1.f - e) / (1.f + e);
-    return x < 0.f ? -t : t;
+    return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.f;
 }
 
 struct LstmFwdParams {
@@ -82,77 +84,70 @@ __global__ void lstm_pack_kernel(const __bf16 *in, __bf16 *out, int nmat, int ro
     }
 }
 
-template <int KS>
-struct Frags {
-    bf16x8 a[KS > 0 ? KS : 1], b[KS > 0 ? KS : 1];
-    __device__ __forceinline__ void load(const __bf16 *ap, const __bf16 *bp) {
-        if constexpr (KS > 0) {
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                a[k] = *reinterpret_cast<const bf16x8 *>(ap + k * 512);
-                b[k] = *reinterpret_cast<const bf16x8 *>(bp + k * 512);
-            }
-        }
-    }
-};
-
-template <int KS>
-__device__ __forceinline__ f32x16 mfma_rows(const Frags<KS> &fr, const __bf16 *ap,
-                                            const __bf16 *bp, int H) {
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    if constexpr (KS > 0) {
-#pragma unroll
-        for (int k = 0; k < KS; ++k)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.a[k], fr.b[k], acc, 0, 0, 0);
-    } else {
-#pragma unroll 4
-        for (int k = 0; k < H / 16; ++k) {
-            const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(ap + k * 512);
-            const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(bp + k * 512);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
-        }
-    }
-    return acc;
-}
-
-// grid: x = hidden tile (H/32), y = batch tile (ceil(B/32)), z = direction
+// grid: x = hidden tile (H/32), y = batch tile group (ceil(Bp/(32*BT))), z = direction
 #ifdef ASR_LSTM_STAMPS
 #define STAMP(i) stamp[i] = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(i) do {} while (0)
 #endif
 
-template <int KS>
+// One time step of the forward recurrence for a [32*BT batch] x [32 hidden]
+// tile (all four gates).  KS = H/16 k-steps (compile time).  Wave g owns gate
+// g: its W_hh fragments (KS x 16 B per lane) are loaded straight to registers,
+// the h_{t-1} tile — needed by all four waves — is staged once through LDS.
+// BT = 2 halves the W_hh re-reads per step (the kernel is bound by operand
+// fetch from L2 / Infinity Cache, not by the MFMAs).
+template <int KS, int BT>
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
 #ifdef ASR_LSTM_STAMPS
     unsigned long long stamp[4];
     const unsigned long long stamp_start = __builtin_amdgcn_s_memtime();
 #endif
-    __shared__ float g_lds[4][32][33];
+    __shared__ __attribute__((aligned(16))) __bf16 a_lds[BT * KS * 512];
+    __shared__ float g_lds[BT][4][32][33];
     const int H = p.H, B = p.B;
-    const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32, dir = blockIdx.z;
+    const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32 * BT, dir = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = dir == 0 ? p.step : p.T - 1 - p.step;
-    const int Bp = (B + 31) & ~31, KSr = H / 16;
+    const int Bp = (B + 63) & ~63;
     const __bf16 *hprev = p.hbuf + ((size_t)(p.step & 1) * 2 + dir) * Bp * H;
     __bf16 *hnext = p.hbuf + ((size_t)((p.step + 1) & 1) * 2 + dir) * Bp * H;
 
-    // ---- MFMA fragments first: vmcnt retires in order, so the (L2-resident)
-    // fragment loads must not queue behind the HBM loads of the pointwise phase
-    const __bf16 *fr_ap = hprev + ((size_t)blockIdx.y * KSr * 64 + lane) * 8;
-    const __bf16 *fr_bp = p.whh + ((size_t)(dir * 4 + wave) * H * H) +
-                          ((size_t)blockIdx.x * KSr * 64 + lane) * 8;
-    Frags<KS> fr;
-    fr.load(fr_ap, fr_bp);
+    // ---- W_hh fragments of this wave's gate (vmcnt retires in order: keep the
+    // L2-resident operand loads ahead of the HBM loads of the pointwise phase)
+    bf16x8 fb[KS];
+    {
+        const __bf16 *bp = p.whh + ((size_t)(dir * 4 + wave) * H * H) +
+                           ((size_t)blockIdx.x * KS * 64 + lane) * 8;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) fb[k] = *reinterpret_cast<const bf16x8 *>(bp + k * 512);
+    }
+    // ---- h_{t-1} tile(s): BT*KS KiB, contiguous in fragment-major order
+    {
+        const bf16x8 *src = reinterpret_cast<const bf16x8 *>(
+            hprev + (size_t)blockIdx.y * BT * KS * 512);
+        bf16x8 *dst = reinterpret_cast<bf16x8 *>(a_lds);
+        constexpr int CH = BT * KS * 64;            // 16-byte chunks
+        bf16x8 tmp[(CH + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (CH + 255) / 256; ++i) {
+            const int c = i * 256 + threadIdx.x;
+            if (c < CH) tmp[i] = src[c];
+        }
+#pragma unroll
+        for (int i = 0; i < (CH + 255) / 256; ++i) {
+            const int c = i * 256 + threadIdx.x;
+            if (c < CH) dst[c] = tmp[i];
+        }
+    }
     STAMP(0);
 
     // ---- operands of the pointwise phase: issued now, consumed after the GEMM
-    float pgx[4][4], pc[4];
-    bool pact[4];
+    constexpr int NE = 4 * BT;
+    float pgx[NE][4], pc[NE];
+    bool pact[NE];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int idx = e * 256 + threadIdx.x;
         const int b = b0 + (idx >> 5), j = j0 + (idx & 31);
         const int bc = b < B ? b : B - 1;
@@ -162,56 +157,70 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
         for (int g = 0; g < 4; ++g) pgx[e][g] = gxp[g * H];
         pc[e] = p.cbuf[((size_t)dir * B + bc) * H + j];
     }
+    __syncthreads();
 
-    // ---- gate pre-activation tile: [32 batch] x [32 hidden of gate `wave`]
+    // ---- gate pre-activation tiles
     {
-        const f32x16 acc = mfma_rows<KS>(fr, fr_ap, fr_bp, H);
+        f32x16 acc[BT];
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[bt][i] = 0.f;
+        const bf16x8 *al = reinterpret_cast<const bf16x8 *>(a_lds) + lane;
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt)
+                acc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[(bt * KS + k) * 64], fb[k],
+                                                                  acc[bt], 0, 0, 0);
         STAMP(1);
         const int col = lane & 31;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            g_lds[wave][row][col] = acc[i];
-        }
+        for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                g_lds[bt][wave][row][col] = acc[bt][i];
+            }
     }
     __syncthreads();
     STAMP(2);
 
-    // ---- pointwise cell update: 1024 (b, j) elements over 256 threads
+    // ---- pointwise cell update: BT*1024 (b, j) elements over 256 threads
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int idx = e * 256 + threadIdx.x;
-        const int row = idx >> 5, col = idx & 31;
-        const int b = b0 + row, j = j0 + col;
+        const int rowg = idx >> 5, col = idx & 31;
+        const int bt = rowg >> 5, row = rowg & 31;
+        const int b = b0 + rowg, j = j0 + col;
         if (b < B) {
-        const bool active = pact[e];
-        const size_t sidx = ((size_t)dir * B + b) * H + j;
-        float *yo = p.y + (((size_t)t * B + b) * 2 + dir) * H + j;
-        __bf16 *ybo = p.ybf + (((size_t)dir * (p.T + 2) + t + 1) * B + b) * H + j;
-        const size_t gsave = ((((size_t)t * 2 + dir) * B + b) * 4) * H + j;
-        const size_t csv = (((size_t)t * 2 + dir) * B + b) * H + j;
-        if (active) {
-            const float gi = sigmoidf_(g_lds[0][row][col] + pgx[e][0]);
-            const float gf = sigmoidf_(g_lds[1][row][col] + pgx[e][1]);
-            const float gg = tanhf_(g_lds[2][row][col] + pgx[e][2]);
-            const float go = sigmoidf_(g_lds[3][row][col] + pgx[e][3]);
-            const float c = gf * pc[e] + gi * gg;
-            const float h = go * tanhf_(c);
-            p.cbuf[sidx] = c;
-            hnext[frag_off(b, j, KSr)] = (__bf16)h;
-            *yo = h;
-            *ybo = (__bf16)h;
-            p.gates[gsave] = gi;
-            p.gates[gsave + H] = gf;
-            p.gates[gsave + 2 * H] = gg;
-            p.gates[gsave + 3 * H] = go;
-            p.csave[csv] = c;
-        } else {
-            hnext[frag_off(b, j, KSr)] = hprev[frag_off(b, j, KSr)];
-            *yo = 0.f;
-            *ybo = (__bf16)0.f;
-            p.csave[csv] = pc[e];
-        }
+            const size_t sidx = ((size_t)dir * B + b) * H + j;
+            float *yo = p.y + (((size_t)t * B + b) * 2 + dir) * H + j;
+            __bf16 *ybo = p.ybf + (((size_t)dir * (p.T + 2) + t + 1) * B + b) * H + j;
+            const size_t gsave = ((((size_t)t * 2 + dir) * B + b) * 4) * H + j;
+            const size_t csv = (((size_t)t * 2 + dir) * B + b) * H + j;
+            if (pact[e]) {
+                const float gi = sigmoidf_(g_lds[bt][0][row][col] + pgx[e][0]);
+                const float gf = sigmoidf_(g_lds[bt][1][row][col] + pgx[e][1]);
+                const float gg = tanhf_(g_lds[bt][2][row][col] + pgx[e][2]);
+                const float go = sigmoidf_(g_lds[bt][3][row][col] + pgx[e][3]);
+                const float c = gf * pc[e] + gi * gg;
+                const float h = go * tanhf_(c);
+                p.cbuf[sidx] = c;
+                hnext[frag_off(b, j, KS)] = (__bf16)h;
+                *yo = h;
+                *ybo = (__bf16)h;
+                p.gates[gsave] = gi;
+                p.gates[gsave + H] = gf;
+                p.gates[gsave + 2 * H] = gg;
+                p.gates[gsave + 3 * H] = go;
+                p.csave[csv] = c;
+            } else {
+                hnext[frag_off(b, j, KS)] = hprev[frag_off(b, j, KS)];
+                *yo = 0.f;
+                *ybo = (__bf16)0.f;
+                p.csave[csv] = pc[e];
+            }
         }
     }
     STAMP(3);
@@ -238,30 +247,46 @@ struct LstmBwdParams {
     int step;
 };
 
-template <int KS>
+// One time step of the backward recurrence for a [32*BT batch] x [32 hidden]
+// tile: dh_rec[b][j] = sum_k dgates_prev[b][k] * W_hh[k][j] with K = 4H split
+// over the four waves (wave w takes the columns of gate w), then the LSTM cell
+// backward in fp32.
+template <int KS, int BT>
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
-    __shared__ float part[4][32][33];
+    __shared__ float part[BT][4][32][33];
     const int H = p.H, B = p.B, H4 = 4 * p.H;
-    const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32, dir = blockIdx.z;
+    const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32 * BT, dir = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // the backward scan visits frames in the opposite order of the forward one
     const int t = dir == 0 ? p.T - 1 - p.step : p.step;
-    const int Bp = (B + 31) & ~31, KSr = H / 16, KS4 = H4 / 16;
+    const int Bp = (B + 63) & ~63;
+    constexpr int KS4 = 4 * KS;
     const __bf16 *dgprev = p.dgbuf + ((size_t)(p.step & 1) * 2 + dir) * Bp * H4;
     __bf16 *dgnext = p.dgbuf + ((size_t)((p.step + 1) & 1) * 2 + dir) * Bp * H4;
 
-    // wave w covers k-steps [w*KSr, (w+1)*KSr) of K = 4H (the columns of gate w)
-    const __bf16 *fr_ap = dgprev + (((size_t)blockIdx.y * KS4 + (size_t)wave * KSr) * 64 + lane) * 8;
-    const __bf16 *fr_bp = p.whhT + (size_t)dir * H * H4 +
-                          (((size_t)blockIdx.x * KS4 + (size_t)wave * KSr) * 64 + lane) * 8;
-    Frags<KS> fr;
-    fr.load(fr_ap, fr_bp);
+    // ---- operands: W_hhᵀ slice of this wave (registers) and the dgates tiles
+    bf16x8 fb[KS], fa[BT][KS];
+    {
+        const __bf16 *bp = p.whhT + (size_t)dir * H * H4 +
+                           (((size_t)blockIdx.x * KS4 + (size_t)wave * KS) * 64 + lane) * 8;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) fb[k] = *reinterpret_cast<const bf16x8 *>(bp + k * 512);
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            const __bf16 *ap = dgprev + ((((size_t)blockIdx.y * BT + bt) * KS4 +
+                                          (size_t)wave * KS) * 64 + lane) * 8;
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+                fa[bt][k] = *reinterpret_cast<const bf16x8 *>(ap + k * 512);
+        }
+    }
 
     // ---- operands of the pointwise phase: issued now, consumed after the GEMM
-    float pg[4][4], pcs[4], pcp[4], pdy[4], pdc[4];
-    bool pact[4];
+    constexpr int NE = 4 * BT;
+    float pg[NE][4], pcs[NE], pcp[NE], pdy[NE], pdc[NE];
+    bool pact[NE];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int idx = e * 256 + threadIdx.x;
         const int b = b0 + (idx >> 5), j = j0 + (idx & 31);
         const int bc = b < B ? b : B - 1;
@@ -279,56 +304,62 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
         pdc[e] = p.dcbuf[((size_t)dir * B + bc) * H + j];
     }
 
-    // ---- dh_rec[b][j] = sum_k dgates_prev[b][k] * W_hh[k][j]; K = 4H split
-    // over the four waves (wave w takes the columns of gate w)
     {
-        const f32x16 acc = mfma_rows<KS>(fr, fr_ap, fr_bp, H);
         const int col = lane & 31;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            part[wave][row][col] = acc[i];
+        for (int bt = 0; bt < BT; ++bt) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[bt][k], fb[k], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                part[bt][wave][row][col] = acc[i];
+            }
         }
     }
     __syncthreads();
 
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int idx = e * 256 + threadIdx.x;
-        const int row = idx >> 5, col = idx & 31;
-        const int b = b0 + row, j = j0 + col;
+        const int rowg = idx >> 5, col = idx & 31;
+        const int bt = rowg >> 5, row = rowg & 31;
+        const int b = b0 + rowg, j = j0 + col;
         if (b < B) {
-        const bool active = pact[e];
-        const size_t sidx = ((size_t)dir * B + b) * H + j;
-        __bf16 *dgo = p.dgates + (((size_t)t * B + b) * 2 + dir) * H4 + j;
-        if (active) {
-            const float dh = pdy[e] + (part[0][row][col] + part[1][row][col]) +
-                             (part[2][row][col] + part[3][row][col]);
-            const float gi = pg[e][0], gf = pg[e][1], gg = pg[e][2], go = pg[e][3];
-            const float c = pcs[e];
-            const float cprev = pcp[e];               // cell state the step started from
-            const float tc = tanhf_(c);
-            const float dc = dh * go * (1.f - tc * tc) + pdc[e];
-            const float d_o = dh * tc * go * (1.f - go);
-            const float d_i = dc * gg * gi * (1.f - gi);
-            const float d_f = dc * cprev * gf * (1.f - gf);
-            const float d_g = dc * gi * (1.f - gg * gg);
-            p.dcbuf[sidx] = dc * gf;
-            dgo[0] = (__bf16)d_i; dgo[H] = (__bf16)d_f; dgo[2 * H] = (__bf16)d_g; dgo[3 * H] = (__bf16)d_o;
-            dgnext[frag_off(b, j, KS4)] = (__bf16)d_i;
-            dgnext[frag_off(b, H + j, KS4)] = (__bf16)d_f;
-            dgnext[frag_off(b, 2 * H + j, KS4)] = (__bf16)d_g;
-            dgnext[frag_off(b, 3 * H + j, KS4)] = (__bf16)d_o;
-        } else {
-            // no gradient reaches a padding frame; the carried state gradient
-            // restarts from zero (forward: beyond the end; reverse: before the start)
-            p.dcbuf[sidx] = 0.f;
-            dgo[0] = (__bf16)0.f; dgo[H] = (__bf16)0.f; dgo[2 * H] = (__bf16)0.f; dgo[3 * H] = (__bf16)0.f;
-            dgnext[frag_off(b, j, KS4)] = (__bf16)0.f;
-            dgnext[frag_off(b, H + j, KS4)] = (__bf16)0.f;
-            dgnext[frag_off(b, 2 * H + j, KS4)] = (__bf16)0.f;
-            dgnext[frag_off(b, 3 * H + j, KS4)] = (__bf16)0.f;
-        }
+            const size_t sidx = ((size_t)dir * B + b) * H + j;
+            __bf16 *dgo = p.dgates + (((size_t)t * B + b) * 2 + dir) * H4 + j;
+            if (pact[e]) {
+                const float dh = pdy[e] + (part[bt][0][row][col] + part[bt][1][row][col]) +
+                                 (part[bt][2][row][col] + part[bt][3][row][col]);
+                const float gi = pg[e][0], gf = pg[e][1], gg = pg[e][2], go = pg[e][3];
+                const float tc = tanhf_(pcs[e]);
+                const float dc = dh * go * (1.f - tc * tc) + pdc[e];
+                const float d_o = dh * tc * go * (1.f - go);
+                const float d_i = dc * gg * gi * (1.f - gi);
+                const float d_f = dc * pcp[e] * gf * (1.f - gf);   // pcp: cell state the step started from
+                const float d_g = dc * gi * (1.f - gg * gg);
+                p.dcbuf[sidx] = dc * gf;
+                dgo[0] = (__bf16)d_i; dgo[H] = (__bf16)d_f;
+                dgo[2 * H] = (__bf16)d_g; dgo[3 * H] = (__bf16)d_o;
+                dgnext[frag_off(b, j, KS4)] = (__bf16)d_i;
+                dgnext[frag_off(b, H + j, KS4)] = (__bf16)d_f;
+                dgnext[frag_off(b, 2 * H + j, KS4)] = (__bf16)d_g;
+                dgnext[frag_off(b, 3 * H + j, KS4)] = (__bf16)d_o;
+            } else {
+                // no gradient reaches a padding frame; the carried state gradient
+                // restarts from zero (forward: beyond the end; reverse: before the start)
+                p.dcbuf[sidx] = 0.f;
+                dgo[0] = (__bf16)0.f; dgo[H] = (__bf16)0.f;
+                dgo[2 * H] = (__bf16)0.f; dgo[3 * H] = (__bf16)0.f;
+                dgnext[frag_off(b, j, KS4)] = (__bf16)0.f;
+                dgnext[frag_off(b, H + j, KS4)] = (__bf16)0.f;
+                dgnext[frag_off(b, 2 * H + j, KS4)] = (__bf16)0.f;
+                dgnext[frag_off(b, 3 * H + j, KS4)] = (__bf16)0.f;
+            }
         }
     }
 }
@@ -353,7 +384,7 @@ extern "C" int64_t asr_lstm_workspace_bytes(int B, int H) {
     if (B < 0 || H < 0) return -1;
     // forward: hbuf bf16 [2][2][Bp][H] + cbuf f32 [2][B][H] + packed W_hh
     // backward: dgbuf bf16 [2][2][Bp][4H] + dcbuf f32 [2][B][H] + packed W_hhᵀ (larger)
-    const int64_t Bp = (B + 31) / 32 * 32;
+    const int64_t Bp = (B + 63) / 64 * 64;
     return (int64_t)2 * 2 * Bp * 4 * H * 2 + (int64_t)2 * B * H * 4 +
            (int64_t)2 * 4 * H * H * 2 + 256;
 }
@@ -371,7 +402,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmFwdParams p;
-    const size_t Bp = (size_t)(B + 31) / 32 * 32;
+    const size_t Bp = (size_t)(B + 63) / 64 * 64;
     const size_t hbytes = (size_t)2 * 2 * Bp * H * 2, cbytes = (size_t)2 * B * H * 4;
     __bf16 *wpack = (__bf16 *)((char *)workspace + hbytes + cbytes);
     p.gx = gx; p.whh = wpack; p.lens = lens;
@@ -388,11 +419,20 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
     // [2 dir x 4 gates] matrices of H x H (rows = hidden unit, cols = k)
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
                        (const __bf16 *)whh_bf16, wpack, 8, H, H, 0);
-    const dim3 grid(H / 32, (B + 31) / 32, 2);
+    // 64-row batch tiles once the grid still fills the chip, else 32-row tiles
+    // 64-row tiles (bt = 2) halve the W_hh re-reads but were measured SLOWER (13.7 vs
+    // 11.4 us at B=512): the step is latency-bound per workgroup, not fetch-bound
+    const int bt = 1;
+    const dim3 grid(H / 32, (B + 32 * bt - 1) / (32 * bt), 2);
+    void (*kern)(LstmFwdParams) = nullptr;
+#define ASR_PICK(KSV)                                                              \
+    if (H == 16 * KSV) kern = bt == 2 ? lstm_fwd_step_kernel<KSV, 2> : lstm_fwd_step_kernel<KSV, 1>;
+    ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32) ASR_PICK(48)
+#undef ASR_PICK
+    if (!kern) return ASR_EUNSUPPORTED;       // hidden sizes built: 64,128,256,320,384,512,768
     for (int step = 0; step < T; ++step) {
         p.step = step;
-        if (H == 320) hipLaunchKernelGGL(lstm_fwd_step_kernel<20>, grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(lstm_fwd_step_kernel<0>, grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, p);
     }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
@@ -410,7 +450,7 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmBwdParams p;
-    const size_t Bp = (size_t)(B + 31) / 32 * 32;
+    const size_t Bp = (size_t)(B + 63) / 64 * 64;
     const size_t dbytes = (size_t)2 * 2 * Bp * 4 * H * 2, cbytes = (size_t)2 * B * H * 4;
     __bf16 *wpack = (__bf16 *)((char *)workspace + dbytes + cbytes);
     p.dy = dy; p.whhT = wpack; p.lens = lens;
@@ -423,11 +463,19 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
     // whhT_bf16 is [2][H][4H] row-major: rows = hidden unit j, cols = k over 4H
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
                        (const __bf16 *)whhT_bf16, wpack, 2, H, 4 * H, 0);
-    const dim3 grid(H / 32, (B + 31) / 32, 2);
+    // 64-row tiles (bt = 2) halve the W_hh re-reads but were measured SLOWER (13.7 vs
+    // 11.4 us at B=512): the step is latency-bound per workgroup, not fetch-bound
+    const int bt = 1;
+    const dim3 grid(H / 32, (B + 32 * bt - 1) / (32 * bt), 2);
+    void (*kern)(LstmBwdParams) = nullptr;
+#define ASR_PICK(KSV)                                                              \
+    if (H == 16 * KSV) kern = bt == 2 ? lstm_bwd_step_kernel<KSV, 2> : lstm_bwd_step_kernel<KSV, 1>;
+    ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32) ASR_PICK(48)
+#undef ASR_PICK
+    if (!kern) return ASR_EUNSUPPORTED;
     for (int step = 0; step < T; ++step) {
         p.step = step;
-        if (H == 320) hipLaunchKernelGGL(lstm_bwd_step_kernel<20>, grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(lstm_bwd_step_kernel<0>, grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, p);
     }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
