@@ -141,6 +141,39 @@ int asr_argmax_rows_f32(const float *x, int64_t rows, int C, int32_t *out_idx,
                         void *stream);
 
 /*
+ * Forward-backward / alpha scan over GROUP-FACTORED graphs: the reference's CTC
+ * decoding graphs (build_ctc_mono_decoding_fst fst_utils.py:679-726,
+ * build_ctc_bigram_decoding_fst :729-835), i.e. the denominator graph of the
+ * globally normalised loss (advanced_decoder.py:473,497-500) and the search
+ * graph of FSTDecoder.decode (:542-554).  State s1 feeds group g_of[s1]; state
+ * s2 accepts an arc from every s1 with g_of[s1] == h_of[s2], plus an extra
+ * self-loop when selfx[s2]; every arc into s2 consumes label[s2] with weight 0;
+ * the start state is 0.  Same results as asr_lattice_fwbw_f32 /
+ * asr_lattice_forward_f32 on the equivalent padded arc matrices (up to fp32
+ * summation order) at ~1/17 of the arithmetic for the 2401-state bigram graph.
+ *   g_of, h_of, label, selfx, uniq [N] i32 (uniq: no other state has this label)
+ *   mem_g [G,Wg], mem_h [G,Wh] i32: states of every group, ascending, -1 padded
+ *   term [N] f32 terminal log-weights
+ * Outputs / workspace as for the generic entry points;
+ * workspace: asr_lattice_grouped_workspace_bytes(T,B,N,G).  Needs 16*G <= 1024.
+ */
+int64_t asr_lattice_grouped_workspace_bytes(int T, int B, int N, int G);
+
+int asr_lattice_grouped_fwbw_f32(
+    const float *lp, int T, int B, int C, const int32_t *lens, int N, int G, int Wg, int Wh,
+    const int32_t *g_of, const int32_t *h_of, const int32_t *label, const int32_t *selfx,
+    const int32_t *uniq, const int32_t *mem_g, const int32_t *mem_h, const float *term,
+    float neg_inf, float *out_logZ, float *out_grad, float *out_logZ_bwd, void *workspace,
+    int64_t workspace_bytes, void *stream);
+
+int asr_lattice_grouped_forward_f32(
+    const float *lp, int T, int B, int C, const int32_t *lens, int N, int G, int Wg, int Wh,
+    const int32_t *g_of, const int32_t *h_of, const int32_t *label, const int32_t *selfx,
+    const int32_t *uniq, const int32_t *mem_g, const int32_t *mem_h, const float *term,
+    float neg_inf, int viterbi, float *out_score, int32_t *out_best_il, void *workspace,
+    int64_t workspace_bytes, void *stream);
+
+/*
  * Bidirectional, bias-free LSTM recurrence on a padded, length-masked batch —
  * the sequential part of BatchRNN (modules/encoders/encoder_utils.py:55-124:
  * nn.LSTM(bidirectional=True, bias=False) applied to a PackedSequence).

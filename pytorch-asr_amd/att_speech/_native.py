@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -40,6 +40,11 @@ _SIGNATURES = {
     'asr_log_softmax_bwd_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'asr_sub_rowmax_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_argmax_rows_f32': (_i, [_vp, _i64, _i, _vp, _vp]),
+    'asr_lattice_grouped_workspace_bytes': (_i64, [_i, _i, _i, _i]),
+    'asr_lattice_grouped_fwbw_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i] + [_vp] * 8 +
+                                     [_f, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'asr_lattice_grouped_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i] + [_vp] * 8 +
+                                        [_f, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_workspace_bytes': (_i64, [_i, _i]),
     'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -260,3 +265,59 @@ def lstm_bidir_bwd(dy, whhT_bf16, lens, gates, csave):
                                     _p(csave), _p(dgates), _p(ws), nbytes, _stream()),
           'asr_lstm_bidir_bwd_bf16')
     return dgates
+
+
+class GroupedGraph(object):
+    """Device copy of a group-factored decoding graph (include/asr_amd.h,
+    asr_lattice_grouped_*): numpy/torch arrays g_of, h_of, label, selfx, uniq [N],
+    mem_g [G,Wg], mem_h [G,Wh], term [N]."""
+
+    def __init__(self, st, device):
+        def i32(a):
+            return torch.as_tensor(a).to(device=device, dtype=torch.int32).contiguous()
+        self.g_of, self.h_of, self.label = i32(st['g_of']), i32(st['h_of']), i32(st['label'])
+        self.selfx, self.uniq = i32(st['selfx']), i32(st['uniq'])
+        self.mem_g, self.mem_h = i32(st['mem_g']), i32(st['mem_h'])
+        self.term = torch.as_tensor(st['term']).to(device=device, dtype=torch.float32).contiguous()
+        self.N = int(self.g_of.numel())
+        self.G, self.Wg = self.mem_g.shape
+        self.Wh = self.mem_h.shape[1]
+
+    def _args(self):
+        return (self.N, self.G, self.Wg, self.Wh, _p(self.g_of), _p(self.h_of), _p(self.label),
+                _p(self.selfx), _p(self.uniq), _p(self.mem_g), _p(self.mem_h), _p(self.term))
+
+
+def grouped_fwbw(lp, lens, gg, neg_inf=-1e20, want_bwd_total=False):
+    """asr_lattice_grouped_fwbw_f32 -> (logZ [B], grad [T,B,C], logZ_bwd | None)."""
+    lp = _dev(lp, torch.float32, 'log_probs')
+    lens = _dev(lens, torch.int32, 'act_lens')
+    T, B, C = lp.shape
+    L = lib()
+    logZ = torch.empty(B, dtype=torch.float32, device=lp.device)
+    grad = torch.empty_like(lp)
+    zb = torch.empty(B, dtype=torch.float32, device=lp.device) if want_bwd_total else None
+    nbytes = L.asr_lattice_grouped_workspace_bytes(T, B, gg.N, gg.G)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=lp.device)
+    check(L.asr_lattice_grouped_fwbw_f32(
+        _p(lp), T, B, C, _p(lens), *gg._args(), float(neg_inf), _p(logZ), _p(grad), _p(zb),
+        _p(ws), nbytes, _stream()), 'asr_lattice_grouped_fwbw_f32')
+    return logZ, grad, zb
+
+
+def grouped_forward(lp, lens, gg, neg_inf=-1e20, viterbi=False, want_path=False):
+    """asr_lattice_grouped_forward_f32 -> (score [B], best_il [T,B] | None)."""
+    lp = _dev(lp, torch.float32, 'log_probs')
+    lens = _dev(lens, torch.int32, 'act_lens')
+    T, B, C = lp.shape
+    L = lib()
+    score = torch.empty(B, dtype=torch.float32, device=lp.device)
+    best, ws, nbytes = None, None, 0
+    if viterbi and want_path:
+        best = torch.empty((T, B), dtype=torch.int32, device=lp.device)
+        nbytes = L.asr_lattice_grouped_workspace_bytes(T, B, gg.N, gg.G)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=lp.device)
+    check(L.asr_lattice_grouped_forward_f32(
+        _p(lp), T, B, C, _p(lens), *gg._args(), float(neg_inf), int(bool(viterbi)), _p(score),
+        _p(best), _p(ws), nbytes, _stream()), 'asr_lattice_grouped_forward_f32')
+    return score, best

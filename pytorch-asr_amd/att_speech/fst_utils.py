@@ -94,6 +94,21 @@ def in_to_out_edge_matrices(graph_matrices, nc_weight=NEG_INF):
             torch.from_numpy(term.copy()))
 
 
+class GraphMatrices(list):
+    """The reference's list of 4 / 8 padded graph tensors, optionally carrying
+    the group-factored description of the same graph (`grouped`, see
+    DecodingTransducer.grouped_structure) so that path_reduction can use the
+    closed-form kernels; slicing keeps the tag."""
+    grouped = None
+
+    def __getitem__(self, idx):
+        out = list.__getitem__(self, idx)
+        if isinstance(idx, slice):
+            out = GraphMatrices(out)
+            out.grouped = self.grouped
+        return out
+
+
 # ----------------------------------------------------------------------------
 # lattice reductions on the GPU
 # ----------------------------------------------------------------------------
@@ -131,6 +146,23 @@ def _device_graph(graph_matrices, device):
     return g
 
 
+_grouped_cache = {}
+
+
+def _device_grouped(graph_matrices, device):
+    """GroupedGraph for matrices tagged by CTCGraphGen.get_decoding_matrices,
+    else None."""
+    st = getattr(graph_matrices, 'grouped', None)
+    if st is None:
+        return None
+    key = (id(st), str(device))
+    hit = _grouped_cache.get(key)
+    if hit is None or hit[0] is not st:
+        hit = (st, _native.GroupedGraph(st, device))
+        _grouped_cache[key] = hit
+    return hit[1]
+
+
 class PathLogSumExp(torch.autograd.Function):
     """Forward-backward in the log semiring; same contract as the reference's
     PathLogSumExp (fst_utils.py:400-488): returns +logZ per utterance, the
@@ -140,12 +172,17 @@ class PathLogSumExp(torch.autograd.Function):
     def forward(ctx, log_probs, act_lens, graph_matrices, neg_inf=-np.inf):
         log_probs = log_probs.detach()
         _assert_sorted(act_lens)
-        graph = _device_graph(graph_matrices, log_probs.device)
-        if graph.dst_out is None:
-            raise AssertionError("PathLogSumExp needs the 8 graph matrices")
         if not np.isfinite(neg_inf):
             neg_inf = NEG_INF
         lens = _lens_on(act_lens, log_probs.device)
+        grouped = _device_grouped(graph_matrices, log_probs.device)
+        if grouped is not None:                   # closed-form decoding graph
+            log_cost, grads, _ = _native.grouped_fwbw(log_probs, lens, grouped, neg_inf)
+            ctx.grads = grads
+            return log_cost
+        graph = _device_graph(graph_matrices, log_probs.device)
+        if graph.dst_out is None:
+            raise AssertionError("PathLogSumExp needs the 8 graph matrices")
         log_cost, grads, _ = _native.lattice_fwbw(log_probs, lens, graph, neg_inf)
         ctx.grads = grads
         return log_cost
@@ -166,8 +203,12 @@ class _PathViterbi(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_probs, act_lens, graph, neg_inf):
         lens = _lens_on(act_lens, log_probs.device)
-        score, best = _native.lattice_forward(log_probs.detach(), lens, graph,
-                                              neg_inf, viterbi=True, want_path=True)
+        if isinstance(graph, _native.GroupedGraph):
+            score, best = _native.grouped_forward(log_probs.detach(), lens, graph,
+                                                  neg_inf, viterbi=True, want_path=True)
+        else:
+            score, best = _native.lattice_forward(log_probs.detach(), lens, graph,
+                                                  neg_inf, viterbi=True, want_path=True)
         ctx.save_for_backward(best, lens)
         ctx.shape = log_probs.shape
         ctx.mark_non_differentiable(best)
@@ -186,7 +227,9 @@ class _PathViterbi(torch.autograd.Function):
 
 def viterbi_path(log_probs, act_lens, graph_matrices, neg_inf=NEG_INF):
     """(score [B], best input label per frame [T,B] int32) of the best path."""
-    graph = _device_graph(graph_matrices, log_probs.device)
+    graph = _device_grouped(graph_matrices, log_probs.device)
+    if graph is None:
+        graph = _device_graph(graph_matrices, log_probs.device)
     return _PathViterbi.apply(log_probs, act_lens, graph, neg_inf)
 
 
@@ -205,9 +248,14 @@ def path_reduction(log_probs, act_lens, graph_matrices, red_kind='logsumexp',
 
     if red_kind in ['logsumexp', 'logsumexp_autodiff']:
         if not log_probs.requires_grad:
-            graph = _device_graph(graph_matrices[:4], log_probs.device)
             lens = _lens_on(act_lens, log_probs.device)
+            grouped = _device_grouped(graph_matrices, log_probs.device)
+            if grouped is not None:
+                return _native.grouped_forward(log_probs, lens, grouped, neg_inf)[0]
+            graph = _device_graph(graph_matrices[:4], log_probs.device)
             return _native.lattice_forward(log_probs, lens, graph, neg_inf)[0]
+        if getattr(graph_matrices, 'grouped', None) is not None:
+            return path_logsumexp(log_probs, act_lens, graph_matrices, neg_inf)
         # differentiable: explicit beta scan needs the out-edge form
         if len(graph_matrices) == 4:
             graph_matrices = list(graph_matrices) + list(
@@ -324,6 +372,39 @@ class DecodingTransducer(object):
             il = np.concatenate([il, sl])
             ol = np.concatenate([ol, np.zeros_like(sl)])
         return src, dst, il, ol
+
+    def grouped_structure(self, nc_weight=NEG_INF):
+        """Group factorisation of the graph (see include/asr_amd.h,
+        asr_lattice_grouped_*): state s1 feeds group g_of[s1]; state s2 accepts
+        from every s1 with g_of[s1] == h_of[s2] plus its extra self-loop."""
+        S, N = self.S, self.num_states
+        s = np.arange(N)
+        if self.context_order == 1:
+            g_of = np.zeros(N, np.int64)
+            h_of = np.zeros(N, np.int64)
+            label = s.copy()
+            selfx = np.zeros(N, np.int64)
+            G = 1
+        else:
+            c, l = s // S, s % S
+            g_of = np.where(l == 0, c, l)
+            h_of = c
+            label = np.where((l != 0) | self.use_contextual_blanks, c * S + l, 0)
+            selfx = ((l != 0) & (c != l)).astype(np.int64) * int(self.allow_nonblank_selfloops)
+            G = S
+
+        def members(of):
+            lists = [np.nonzero(of == grp)[0] for grp in range(G)]
+            w = max(1, max(len(x) for x in lists))
+            m = np.full((G, w), -1, np.int64)
+            for grp, x in enumerate(lists):
+                m[grp, :len(x)] = x
+            return m
+        counts = np.bincount(label, minlength=S ** self.context_order)
+        return dict(g_of=g_of, h_of=h_of, label=label, selfx=selfx,
+                    uniq=(counts[label] == 1).astype(np.int64),
+                    mem_g=members(g_of), mem_h=members(h_of),
+                    term=np.zeros(N, np.float32))
 
     def transition_tables(self):
         """dense [num_states, num_classes] next-state / output tables
@@ -518,7 +599,9 @@ class BaseGraphGen(object):
             d.num_states, src, dst, il, np.zeros(len(src), np.float32),
             np.zeros(d.num_states, np.float32), self.nc_weight,
             self.for_forward_only)
-        self.decoding_mats[key] = [m.unsqueeze(0).to(device) for m in mats]
+        tagged = GraphMatrices(m.unsqueeze(0).to(device) for m in mats)
+        tagged.grouped = d.grouped_structure(self.nc_weight)
+        self.decoding_mats[key] = tagged
         return self.decoding_mats[key]
 
 

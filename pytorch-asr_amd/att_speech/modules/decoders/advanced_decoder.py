@@ -392,7 +392,7 @@ class FSTDecoder(BaseDecoder):
         # best state sequence of the decoding graph; the reference gets the
         # same indices from the autograd gradient of the Viterbi score (:546-554)
         _, selidx = fst_utils.viterbi_path(
-            logits.detach(), encoded_lens, denominator_matrices[:4],
+            logits.detach(), encoded_lens, denominator_matrices,
             self.graph_generator.nc_weight)
         selidx = selidx.cpu().numpy()
         lens = [int(l) for l in torch.as_tensor(encoded_lens).tolist()]

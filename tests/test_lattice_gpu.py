@@ -175,6 +175,55 @@ def test_generic_graph_with_per_arc_labels(oracle_lib):
     np.testing.assert_allclose(zb, want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
 
 
+GROUPED = [
+    ('mono_s49', 1, 49, {}, 60, 5),
+    ('bi_s7', 2, 7, {}, 50, 6),
+    ('bi_s7_ctxblank', 2, 7, dict(use_contextual_blanks=True), 40, 4),
+    ('bi_s7_noself', 2, 7, dict(allow_nonblank_selfloops=False), 40, 4),
+    ('bi_s49', 2, 49, {}, 14, 3),                   # the 2401-state x 51-arc CTC-G denominator
+]
+
+
+@pytest.mark.parametrize('name,order,S,kw,T,B', GROUPED, ids=[g[0] for g in GROUPED])
+def test_grouped_decoding_graph_kernels(oracle_lib, name, order, S, kw, T, B):
+    """Closed-form (group-factored) kernels for the decoding / denominator
+    graphs against the oracle's generic sparse scan on the padded arc matrices
+    of the SAME graph (fst_utils.py:662-676)."""
+    from att_speech import _native, fst_utils as P
+    rng = np.random.default_rng(len(name) * 7 + S)
+    C = S ** order
+    pg = P.CTCGraphGen(context_order=order, num_symbols=S, graph_build_args=kw)
+    tagged = pg.get_decoding_matrices()
+    assert tagged.grouped is not None and tagged[:4].grouped is not None
+    mats = [m.numpy() for m in tagged]
+    x = rng.standard_normal((T, B, C)).astype(np.float32) * 2
+    lp = x - x.max(-1, keepdims=True)               # what get_fst_loss feeds (:479-484)
+    lens = np.sort(rng.integers(max(1, T // 2), T + 1, size=B))[::-1].astype(np.int32).copy()
+    lens[0] = T
+    want = oracle_lib.path_logsumexp(lp, lens, mats)
+    d = dev()
+    gg = _native.GroupedGraph(tagged.grouped, d)
+    tl = torch.from_numpy(lens).to(d)
+    logZ, grad, zb = _native.grouped_fwbw(torch.from_numpy(lp).to(d), tl, gg, -1e20,
+                                          want_bwd_total=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(logZ.cpu().numpy(), want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), want['grad'], atol=grad_atol(want['logZ']))
+    np.testing.assert_allclose(zb.cpu().numpy(), want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
+    s, _ = _native.grouped_forward(torch.from_numpy(lp).to(d), tl, gg, -1e20)
+    np.testing.assert_allclose(s.cpu().numpy(), want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
+    vs, vil = oracle_lib.path_forward(lp, lens, mats, viterbi=True)
+    v, best = _native.grouped_forward(torch.from_numpy(lp).to(d), tl, gg, -1e20,
+                                      viterbi=True, want_path=True)
+    np.testing.assert_allclose(v.cpu().numpy(), vs, rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(best.cpu().numpy(), vil)        # bit-exact labels
+    # and through the reference-shaped surface: tagged matrices take the fast path
+    lpt = torch.from_numpy(lp).to(d).requires_grad_()
+    z = P.path_reduction(lpt, torch.from_numpy(lens), tagged, red_kind='logsumexp')
+    z.sum().backward()
+    np.testing.assert_allclose(lpt.grad.cpu().numpy(), want['grad'], atol=grad_atol(want['logZ']))
+
+
 def test_full_size_properties():
     """BASELINE shape (T'=334, C=49, L<=100) at a saturating batch: properties
     that need no oracle — per-frame posteriors sum to one, zero rows past the

@@ -77,6 +77,24 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         print("%-9s viterbi+path %.3f ms" % (case, e0.elapsed_time(e1) / a.iters))
+        if kind == 'den':
+            gg = _native.GroupedGraph(mats.grouped, dev)
+            for _ in range(2):
+                _native.grouped_fwbw(lp, tl, gg)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(a.iters):
+                _native.grouped_fwbw(lp, tl, gg)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            print("%-9s GROUPED fwbw %.3f ms  (%.1f GB/s algorithmic)" % (case, ms, by / ms / 1e6))
+            e0.record()
+            for _ in range(a.iters):
+                _native.grouped_forward(lp, tl, gg, viterbi=True, want_path=True)
+            e1.record()
+            torch.cuda.synchronize()
+            print("%-9s GROUPED viterbi+path %.3f ms" % (case, e0.elapsed_time(e1) / a.iters))
         e0.record()
         for _ in range(a.iters):
             _native.log_softmax_fwd(x, C)
