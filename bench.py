@@ -36,13 +36,24 @@ HBM_PEAK_GBPS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s sp
 S = 49                                  # egs/wsj/vocabulary.txt
 
 
-def model_config(order=1):
+WORKLOADS = {          # BASELINE.json configs -> (context order, yaml)
+    'ctc': (1, 'ctc'), 'ctc_bi': (2, 'ctc_bi'), 'ctcg_bi_cde': (2, 'ctcg_bi_cde')}
+
+
+def model_config(order=1, workload=None):
     enc = dict(class_name='att_speech.modules.encoders.DeepSpeech2',
                conv_kernel_sizes=[[7, 7], [7, 7]], conv_strides=[[1, 2], [3, 1]],
                rnn_hidden_size=320, rnn_nb_layers=4, rnn_normalization='none')
     dec = dict(class_name='att_speech.modules.decoders.advanced_decoder.FSTDecoder',
                denominator_red='none', normalize_by_dim=0,
                graph_generator=dict(class_name='CTCGraphGen', context_order=order))
+    if workload == 'ctcg_bi_cde':      # egs/wsj/yamls/ctcg_bi_cde.yaml: global normalisation
+        dec = dict(class_name='att_speech.modules.decoders.advanced_decoder.FSTDecoder',
+                   graph_generator=dict(class_name='CTCGraphGen', context_order=2),
+                   embedder='NGramLinear',
+                   embedder_kwargs=dict(bias_only_for_dim=1, num_layers=3,
+                                        embedding_combination_method='concat',
+                                        tied_embeddings=False))
     return enc, dec
 
 
@@ -140,6 +151,8 @@ def main():
     ap.add_argument('--batch', type=int, default=512, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--order', type=int, default=1, help='1 mono-char CTC, 2 bi-char CTC')
+    ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS),
+                    help='BASELINE config; default ctc (mono-char, the headline metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     a = ap.parse_args()
 
@@ -157,10 +170,12 @@ def main():
     from att_speech.dp import FlatGradBucket, broadcast_parameters
     from att_speech.models import SpeechModel
 
+    if a.workload:
+        a.order = WORKLOADS[a.workload][0]
     B, T, order = a.batch, a.frames, a.order
     C = S ** order
     feats, lens, texts, llens = synthetic_batch(B, T, rank, order)
-    enc_cfg, dec_cfg = model_config(order)
+    enc_cfg, dec_cfg = model_config(order, a.workload)
     torch.manual_seed(1234)
     sb = {'features': feats[:2].clone(), 'features_lengths': lens[:2].clone(), 'spkids': None}
     model = SpeechModel(enc_cfg, dec_cfg, sb, C, [str(i) for i in range(S)]).to(dev)
@@ -236,7 +251,7 @@ def main():
                                    'conv+4xBiLSTM-320 encoder + FSTDecoder, fwd+bwd+Adam, '
                                    'synthetic 40-dim x %d-frame fbank'
                                    % ('mono' if order == 1 else 'bi',
-                                      'ctc' if order == 1 else 'ctc_bi', T),
+                                      a.workload or ('ctc' if order == 1 else 'ctc_bi'), T),
                        'batch_per_gpu': B, 'global_batch': B * world, 'frames': T,
                        'classes': C, 'parallelism': 'dp%d' % world,
                        'final_loss': float(loss)},
@@ -246,7 +261,7 @@ def main():
                          'algorithmic_bytes_per_launch': alg,
                          'avg_launch_ms': lat_ms},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload != 'ctcg_bi_cde':
             progress('timing the CPU baseline (about 20 s)')
             res['cpu_baseline'] = cpu_baseline(T, order)
         else:
