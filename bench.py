@@ -183,10 +183,13 @@ def main():
     bucket = FlatGradBucket(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     feats_d = feats.to(dev)                          # inputs resident in HBM
-    # graph matrices are built per batch on the host like the reference's data
-    # workers do (kaldi_dataset.py:230-232) and handed over with the batch
-    graph_matrices = model.decoder.graph_generator.get_training_matrices_batch(texts, llens)
-    n_arcs = (graph_matrices[2] > -1e19).sum((1, 2)).numpy()
+    # The training lattices are built ON the device every step from the labels
+    # (asr_ctc_graph_build; the reference builds them per batch with OpenFst in
+    # its data workers, kaldi_dataset.py:230-232, and copies 8 padded tensors).
+    # The host builder is used once, outside the timed region, to count arcs
+    # for the algorithmic-bytes formula.
+    n_arcs = (model.decoder.graph_generator.get_training_matrices_batch(texts, llens)[2]
+              > -1e19).sum((1, 2)).numpy()
     enc_lens = ((lens + 2) // 3).numpy()
 
     lat_events = []
@@ -196,7 +199,7 @@ def main():
         bucket.zero_()
         if record:
             _native.EVENT_HOOK = lat_events
-        out = model(feats_d, lens, None, texts, llens, graph_matrices=graph_matrices)
+        out = model(feats_d, lens, None, texts, llens)
         _native.EVENT_HOOK = None
         out['loss'].backward()
         bucket.all_reduce_sum()

@@ -141,6 +141,23 @@ int asr_argmax_rows_f32(const float *x, int64_t rows, int C, int32_t *out_idx,
                         void *stream);
 
 /*
+ * Device-side construction of the CTC training lattices for a batch of label
+ * sequences (context orders 1 and 2), directly in the int32 / f32 layout the
+ * lattice entry points take ([B, N = 2*Lmax+1, K = 3], padding arcs at
+ * nc_weight).  Replaces get_training_matrices_batch (fst_utils.py:607-613:
+ * OpenFst compose per utterance + fst_to_matrices :222-294 +
+ * batch_training_graph_matrices :491-521) and the per-step host-to-device copy
+ * of the 8 padded tensors (advanced_decoder.py:457-459).
+ *   labels [B,Lmax] i32 symbols in [1, num_symbols), already reduced modulo
+ *   num_symbols for bigram data sets (fst_utils.py:595-600); label_lens [B].
+ */
+int asr_ctc_graph_build(const int32_t *labels, const int32_t *label_lens, int B, int Lmax,
+                        int num_symbols, int context_order, int allow_nonblank_selfloops,
+                        int use_contextual_blanks, float nc_weight, int32_t *src_in,
+                        int32_t *il_in, float *w_in, float *term, int32_t *dst_out,
+                        int32_t *il_out, float *w_out, void *stream);
+
+/*
  * Forward-backward / alpha scan over GROUP-FACTORED graphs: the reference's CTC
  * decoding graphs (build_ctc_mono_decoding_fst fst_utils.py:679-726,
  * build_ctc_bigram_decoding_fst :729-835), i.e. the denominator graph of the

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -40,6 +40,7 @@ _SIGNATURES = {
     'asr_log_softmax_bwd_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'asr_sub_rowmax_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_argmax_rows_f32': (_i, [_vp, _i64, _i, _vp, _vp]),
+    'asr_ctc_graph_build': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f] + [_vp] * 8),
     'asr_lattice_grouped_workspace_bytes': (_i64, [_i, _i, _i, _i]),
     'asr_lattice_grouped_fwbw_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i] + [_vp] * 8 +
                                      [_f, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -112,6 +113,8 @@ class Graph(object):
                  'w_out', 'Bg', 'N', 'Kin', 'Kout')
 
     def __init__(self, graph_matrices, device):
+        if graph_matrices is None:          # filled in by build_ctc_graph
+            return
         gm = list(graph_matrices)
         if len(gm) not in (4, 8):
             raise AssertionError("expected 4 or 8 graph matrices")
@@ -321,3 +324,32 @@ def grouped_forward(lp, lens, gg, neg_inf=-1e20, viterbi=False, want_path=False)
         _p(lp), T, B, C, _p(lens), *gg._args(), float(neg_inf), int(bool(viterbi)), _p(score),
         _p(best), _p(ws), nbytes, _stream()), 'asr_lattice_grouped_forward_f32')
     return score, best
+
+
+def build_ctc_graph(labels, label_lens, num_symbols, context_order,
+                    allow_nonblank_selfloops=True, use_contextual_blanks=False,
+                    nc_weight=-1e20):
+    """asr_ctc_graph_build: labels [B,Lmax] i32 (GPU), label_lens [B] i32 (GPU)
+    -> Graph with [B, 2*Lmax+1, 3] arc arrays built on the device."""
+    labels = _dev(labels, torch.int32, 'labels')
+    label_lens = _dev(label_lens, torch.int32, 'label_lens')
+    B, Lmax = labels.shape
+    N = 2 * Lmax + 1
+    dev = labels.device
+    g = Graph(None, dev)
+
+    def ti():
+        return torch.empty((B, N, 3), dtype=torch.int32, device=dev)
+
+    def tf():
+        return torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    g.src_in, g.il_in, g.w_in = ti(), ti(), tf()
+    g.dst_out, g.il_out, g.w_out = ti(), ti(), tf()
+    g.term = torch.empty((B, N), dtype=torch.float32, device=dev)
+    g.Bg, g.N, g.Kin, g.Kout = B, N, 3, 3
+    check(lib().asr_ctc_graph_build(
+        _p(labels), _p(label_lens), B, Lmax, int(num_symbols), int(context_order),
+        int(bool(allow_nonblank_selfloops)), int(bool(use_contextual_blanks)),
+        float(nc_weight), _p(g.src_in), _p(g.il_in), _p(g.w_in), _p(g.term),
+        _p(g.dst_out), _p(g.il_out), _p(g.w_out), _stream()), 'asr_ctc_graph_build')
+    return g

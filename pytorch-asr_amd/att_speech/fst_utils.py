@@ -237,6 +237,12 @@ def path_reduction(log_probs, act_lens, graph_matrices, red_kind='logsumexp',
                    neg_inf=NEG_INF):
     """Sum (logsumexp) or max over all paths through per-utterance graphs.
     Same dispatch as the reference (fst_utils.py:322-397)."""
+    if isinstance(graph_matrices, _native.Graph):       # device-built lattice
+        if red_kind in ('logsumexp_fwb', 'logsumexp', 'logsumexp_autodiff'):
+            return path_logsumexp(log_probs, act_lens, graph_matrices, NEG_INF)
+        assert red_kind in ['viterbi', 'viterbi_autodiff']
+        _assert_sorted(act_lens)
+        return _PathViterbi.apply(log_probs, act_lens, graph_matrices, neg_inf)[0]
     if (red_kind == 'logsumexp_fwb' or
             (red_kind == 'logsumexp' and len(graph_matrices) == 8)):
         return path_logsumexp(log_probs, act_lens, graph_matrices, NEG_INF)
@@ -573,6 +579,30 @@ class BaseGraphGen(object):
         if str(device) != 'cpu':
             mats = [m.to(device) for m in mats]
         return mats
+
+    def get_training_graph_device(self, labels, label_lens, device):
+        """Same lattices as get_training_matrices_batch, built ON the device
+        (SURVEY.md §8f N2): only the labels cross PCIe.  Returns the
+        device-resident graph object path_reduction accepts in place of the 8
+        tensors."""
+        if isinstance(label_lens, torch.Tensor):
+            label_lens = label_lens.cpu().numpy()
+        label_lens = np.asarray(label_lens, np.int64)
+        B = len(label_lens)
+        lmax = int(label_lens.max()) if B else 0
+        if isinstance(labels, (list, tuple)):
+            lab = np.zeros((B, lmax), np.int64)
+            for i, row in enumerate(labels):
+                row = np.asarray(row.cpu() if isinstance(row, torch.Tensor) else row)
+                lab[i, :label_lens[i]] = row[:label_lens[i]]
+            labels = lab
+        labels = self._reduce_labels(labels)[:, :lmax]
+        d = self.decoding_fst
+        lab_d = torch.as_tensor(np.ascontiguousarray(labels)).to(device, torch.int32)
+        len_d = torch.as_tensor(label_lens).to(device, torch.int32)
+        return _native.build_ctc_graph(lab_d, len_d, self.num_symbols, self.context_order,
+                                       d.allow_nonblank_selfloops, d.use_contextual_blanks,
+                                       self.nc_weight)
 
     def _batched(self, B, nmax, own, other, il, w, b):
         st, ilab, wt = _arcs_to_matrices(B * nmax, b * nmax + own, other, il, w,

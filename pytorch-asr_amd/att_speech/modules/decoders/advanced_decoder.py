@@ -353,8 +353,10 @@ class FSTDecoder(BaseDecoder):
                                               numerator_matrices2)]) < 1e-10
                 self._verify = True
         else:
-            numerator_matrices = self.graph_generator.get_training_matrices_batch(
-                texts, text_lens, 'cpu')
+            # no graphs in the batch: build the lattices on the device from the
+            # labels (the reference builds them on the host here, :470-471)
+            numerator_matrices = self.graph_generator.get_training_graph_device(
+                texts, text_lens, logits.device)
         lens_dev = torch.as_tensor(encoded_lens).to(logits.device, torch.int32)
         logits, logits_sum = _SubRowMax.apply(logits, lens_dev)     # (:479-484)
         neg_inf = self.graph_generator.nc_weight

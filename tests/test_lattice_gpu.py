@@ -224,6 +224,42 @@ def test_grouped_decoding_graph_kernels(oracle_lib, name, order, S, kw, T, B):
     np.testing.assert_allclose(lpt.grad.cpu().numpy(), want['grad'], atol=grad_atol(want['logZ']))
 
 
+@pytest.mark.parametrize('order,S,kw', [(1, 49, {}), (2, 7, {}), (2, 49, {}),
+                                        (2, 7, dict(use_contextual_blanks=True)),
+                                        (2, 7, dict(allow_nonblank_selfloops=False))])
+def test_device_graph_builder_equals_host_builder(order, S, kw):
+    """asr_ctc_graph_build writes the same arcs as the host
+    closed form (itself bit-equal to the mini-OpenFst composition,
+    tests/test_graphs.py); K is fixed at 3 on the device."""
+    from att_speech import fst_utils as P
+    rng = np.random.default_rng(order * 31 + S)
+    B, Lmax = 9, 12
+    lens = np.array([12, 11, 9, 7, 5, 3, 2, 1, 0])
+    labs = rng.integers(1, min(S, 5), size=(B, Lmax))
+    labs[0, :5] = [2, 2, 2, 3, 3]
+    pg = P.CTCGraphGen(context_order=order, num_symbols=S, graph_build_args=kw)
+    host = pg.get_training_matrices_batch(labs, lens)
+    g = pg.get_training_graph_device(labs, lens, dev())
+    torch.cuda.synchronize()
+
+    def pad3(m, fill):
+        out = torch.full((m.shape[0], m.shape[1], 3), fill, dtype=m.dtype)
+        out[:, :, :m.shape[2]] = m
+        return out
+    for got, want, fill in [(g.src_in, host[0], 0), (g.il_in, host[1], 0), (g.w_in, host[2], -1e20),
+                            (g.dst_out, host[4], 0), (g.il_out, host[5], 0), (g.w_out, host[6], -1e20)]:
+        np.testing.assert_array_equal(got.cpu().numpy(), pad3(want, fill).numpy().astype(got.cpu().numpy().dtype))
+    np.testing.assert_array_equal(g.term.cpu().numpy(), host[3].squeeze(-1).numpy())
+    # and it drives the scan: same loss as with the host-built tensors
+    T = 40
+    lp = torch.log_softmax(torch.from_numpy(
+        rng.standard_normal((T, B, S ** order)).astype(np.float32)), -1).to(dev())
+    tl = torch.full((B,), T, dtype=torch.int32)
+    a = P.path_reduction(lp, tl, g)
+    b2 = P.path_reduction(lp, tl, host)
+    np.testing.assert_allclose(a.cpu().numpy(), b2.cpu().numpy(), rtol=1e-6)
+
+
 def test_full_size_properties():
     """BASELINE shape (T'=334, C=49, L<=100) at a saturating batch: properties
     that need no oracle — per-frame posteriors sum to one, zero rows past the
