@@ -29,6 +29,7 @@
 // frame exactly like pack_padded_sequence does.
 #include "common.h"
 #include "../../include/asr_amd.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,6 +43,35 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 }
 __device__ __forceinline__ float tanhf_(float x) {
     return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.f;
+}
+
+// The cell update and its derivative, shared by the per-step and the persistent
+// kernels.  Contraction is off so both kernels round identically (the tests
+// compare them bit for bit to catch a stale hand-off).
+__device__ __forceinline__ void lstm_cell_fwd(const float pre[4], float cprev, float gate[4],
+                                              float &c, float &h) {
+#pragma clang fp contract(off)
+    gate[0] = sigmoidf_(pre[0]);
+    gate[1] = sigmoidf_(pre[1]);
+    gate[2] = tanhf_(pre[2]);
+    gate[3] = sigmoidf_(pre[3]);
+    c = gate[1] * cprev + gate[0] * gate[2];
+    h = gate[3] * tanhf_(c);
+}
+
+// dh: gradient reaching h_t; dcin: carried dL/dc_t from the later step; cs: c_t;
+// cp: c_{t-1}.  d[] = pre-activation gate gradients (i, f, g, o).
+__device__ __forceinline__ void lstm_cell_bwd(const float g[4], float cs, float cp, float dh,
+                                              float dcin, float d[4], float &dcout) {
+#pragma clang fp contract(off)
+    const float gi = g[0], gf = g[1], gg = g[2], go = g[3];
+    const float tc = tanhf_(cs);
+    const float dc = dh * go * (1.f - tc * tc) + dcin;
+    d[3] = dh * tc * go * (1.f - go);
+    d[0] = dc * gg * gi * (1.f - gi);
+    d[1] = dc * cp * gf * (1.f - gf);
+    d[2] = dc * gi * (1.f - gg * gg);
+    dcout = dc * gf;
 }
 
 struct LstmFwdParams {
@@ -200,12 +230,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
             const size_t gsave = ((((size_t)t * 2 + dir) * B + b) * 4) * H + j;
             const size_t csv = (((size_t)t * 2 + dir) * B + b) * H + j;
             if (pact[e]) {
-                const float gi = sigmoidf_(g_lds[bt][0][row][col] + pgx[e][0]);
-                const float gf = sigmoidf_(g_lds[bt][1][row][col] + pgx[e][1]);
-                const float gg = tanhf_(g_lds[bt][2][row][col] + pgx[e][2]);
-                const float go = sigmoidf_(g_lds[bt][3][row][col] + pgx[e][3]);
-                const float c = gf * pc[e] + gi * gg;
-                const float h = go * tanhf_(c);
+                float pre[4], gt[4], c, h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pre[g] = g_lds[bt][g][row][col] + pgx[e][g];
+                lstm_cell_fwd(pre, pc[e], gt, c, h);
+                const float gi = gt[0], gf = gt[1], gg = gt[2], go = gt[3];
                 p.cbuf[sidx] = c;
                 hnext[frag_off(b, j, KS)] = (__bf16)h;
                 *yo = h;
@@ -335,14 +364,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
             if (pact[e]) {
                 const float dh = pdy[e] + (part[bt][0][row][col] + part[bt][1][row][col]) +
                                  (part[bt][2][row][col] + part[bt][3][row][col]);
-                const float gi = pg[e][0], gf = pg[e][1], gg = pg[e][2], go = pg[e][3];
-                const float tc = tanhf_(pcs[e]);
-                const float dc = dh * go * (1.f - tc * tc) + pdc[e];
-                const float d_o = dh * tc * go * (1.f - go);
-                const float d_i = dc * gg * gi * (1.f - gi);
-                const float d_f = dc * pcp[e] * gf * (1.f - gf);   // pcp: cell state the step started from
-                const float d_g = dc * gi * (1.f - gg * gg);
-                p.dcbuf[sidx] = dc * gf;
+                float d[4], dcout;
+                lstm_cell_bwd(pg[e], pcs[e], pcp[e], dh, pdc[e], d, dcout);   // pcp: cell state the step started from
+                const float d_i = d[0], d_f = d[1], d_g = d[2], d_o = d[3];
+                p.dcbuf[sidx] = dcout;
                 dgo[0] = (__bf16)d_i; dgo[H] = (__bf16)d_f;
                 dgo[2 * H] = (__bf16)d_g; dgo[3 * H] = (__bf16)d_o;
                 dgnext[frag_off(b, j, KS4)] = (__bf16)d_i;
@@ -364,6 +389,317 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Persistent recurrence: ONE launch walks all T steps.  A workgroup (512
+// threads) owns a [32 batch x 64 hidden] tile for the whole sequence: its W_hh
+// fragments (KS x 16 B per lane per wave) and the cell state never leave
+// registers; only h_t (forward) / dgates_t (backward) crosses workgroups, once
+// per step, inside a TEAM = the H/64 workgroups of one (direction, batch tile).
+// Hand-off (MI355X_MICROARCH.md § visibility, sc1 table rows 1/3): the tile is
+// staged in LDS in fragment order and stored as whole 1 KiB blocks, one
+// `buffer_store_dwordx4 sc1` (write-through) per wave; every wave drains
+// vmcnt(0), the workgroup meets at a barrier, ONE lane adds 1 to the team
+// counter (agent scope); consumers poll that counter with an sc1 load from one
+// lane, pass a workgroup barrier, then read the tile with `buffer_load_dwordx4
+// sc1` only.  The grid never exceeds one workgroup per CU (LDS request > 80 KiB
+// and grid <= #CUs, the batch is cut into several launches if needed), so every
+// team mate is resident; every spin is bounded and a timeout poisons the
+// outputs with NaN instead of hanging.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#define ASR_SC1 16
+
+__device__ __forceinline__ bool team_wait(unsigned *ctr, unsigned target, unsigned limit,
+                                          unsigned *err) {
+    for (unsigned it = 0; it < limit; ++it) {
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target)
+            return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+struct LstmTeamCtl {
+    unsigned *ctr;          // [2 dir][nbt] counters, 32 words (128 B) apart, zeroed per call
+    unsigned *err;          // timeout word
+    unsigned spin_limit;
+    int bt0, nbt;           // first batch tile of this launch, batch tiles in total
+};
+
+#define ASR_GLDS_BYTES (4 * 32 * 65 * 4)
+
+template <int KS>
+__global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, LstmTeamCtl ctl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 *a_lds = reinterpret_cast<__bf16 *>(smem);                       // KS KiB
+    float (*g_lds)[32][65] = reinterpret_cast<float (*)[32][65]>(smem + KS * 1024);
+    __bf16 *h_lds = reinterpret_cast<__bf16 *>(smem + KS * 1024 + ASR_GLDS_BYTES);   // 4 KiB
+    __shared__ int dead_s;
+    const int H = p.H, B = p.B, T = p.T;
+    const int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
+    const int j0 = jt * 64, b0 = btile * 32, njt = H / 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int gate = wave >> 1, js = wave & 1;
+    const size_t Bp = (size_t)((B + 63) & ~63);
+    unsigned *myctr = ctl.ctr + ((size_t)dir * ctl.nbt + btile) * 32;
+    if (tid == 0) dead_s = 0;
+
+    bf16x8 fb[KS];
+    {
+        const __bf16 *bp = p.whh + ((size_t)(dir * 4 + gate) * H * H) +
+                           ((size_t)(2 * jt + js) * KS * 64 + lane) * 8;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) fb[k] = *reinterpret_cast<const bf16x8 *>(bp + k * 512);
+    }
+    const __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc(
+        p.hbuf, 0, (int)(2 * 2 * Bp * H * 2), 0x00020000);
+
+    // the thread's four (row, col) elements: row = e*8 + wave, col = lane
+    float c[4];
+    __bf16 hq[4];
+    int len[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int b = b0 + e * 8 + wave;
+        c[e] = 0.f;
+        hq[e] = (__bf16)0.f;
+        len[e] = b < B ? p.lens[b] : 0;
+    }
+    const int col = lane, j = j0 + col;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? step : T - 1 - step;
+        float pgx[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = b0 + e * 8 + wave;
+            const int bc = b < B ? b : B - 1;
+            const float *gxp = p.gx + (((size_t)t * B + bc) * 2 + dir) * 4 * H + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pgx[e][g] = gxp[g * H];
+        }
+        if (step > 0 && tid == 0 && !dead_s) {
+            if (!team_wait(myctr, (unsigned)(njt * step), ctl.spin_limit, ctl.err)) dead_s = 1;
+        }
+        __syncthreads();
+        // ---- h_{t-1} tile of the whole team: KS KiB, sc1 loads only
+        {
+            constexpr int CH = KS * 64, NI = (CH + 511) / 512;
+            const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H +
+                                              (size_t)btile * KS * 512) * 2);
+            u32x4 tmp[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int ch = i * 512 + tid;
+                if (ch < CH) tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(hres, base + ch * 16, 0, ASR_SC1);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int ch = i * 512 + tid;
+                if (ch < CH) reinterpret_cast<u32x4 *>(a_lds)[ch] = tmp[i];
+            }
+        }
+        __syncthreads();
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const bf16x8 *al = reinterpret_cast<const bf16x8 *>(a_lds) + lane;
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[k * 64], fb[k], acc, 0, 0, 0);
+            const int c32 = lane & 31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                g_lds[gate][row][js * 32 + c32] = acc[i];
+            }
+        }
+        __syncthreads();
+        const bool dead = dead_s != 0;
+        float og[4][4], oh[4];
+        bool act[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = e * 8 + wave;
+            act[e] = t < len[e];
+            if (act[e]) {
+                float pre[4], cn;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pre[g] = g_lds[g][row][col] + pgx[e][g];
+                lstm_cell_fwd(pre, c[e], og[e], cn, oh[e]);
+                c[e] = cn;
+                if (dead) oh[e] = __builtin_nanf("");
+                hq[e] = (__bf16)oh[e];
+            } else {
+                oh[e] = 0.f;
+            }
+            h_lds[(((col >> 4) * 64) + row + 32 * ((col >> 3) & 1)) * 8 + (col & 7)] = hq[e];
+        }
+        __syncthreads();
+        if (wave < 4) {
+            const u32x4 v = reinterpret_cast<const u32x4 *>(h_lds)[wave * 64 + lane];
+            const unsigned off = (unsigned)(((((size_t)((step + 1) & 1) * 2 + dir) * Bp * H) +
+                                             ((size_t)btile * KS + 4 * jt + wave) * 512 + lane * 8) * 2);
+            __builtin_amdgcn_raw_buffer_store_b128(v, hres, off, 0, ASR_SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(myctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- outputs nobody inside this launch reads: plain stores, after the signal
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = b0 + e * 8 + wave;
+            if (b < B) {
+                p.y[(((size_t)t * B + b) * 2 + dir) * H + j] = oh[e];
+                p.ybf[(((size_t)dir * (T + 2) + t + 1) * B + b) * H + j] = (__bf16)oh[e];
+                p.csave[(((size_t)t * 2 + dir) * B + b) * H + j] = c[e];
+                if (act[e]) {
+                    const size_t gsave = ((((size_t)t * 2 + dir) * B + b) * 4) * H + j;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) p.gates[gsave + (size_t)g * H] = og[e][g];
+                }
+            }
+        }
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, LstmTeamCtl ctl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KS4 = 4 * KS;
+    __bf16 *a_lds = reinterpret_cast<__bf16 *>(smem);                       // 4*KS KiB
+    float (*part)[32][65] = reinterpret_cast<float (*)[32][65]>(smem + KS4 * 1024);
+    __bf16 *dg_lds = reinterpret_cast<__bf16 *>(smem + KS4 * 1024 + ASR_GLDS_BYTES);   // 16 KiB
+    __shared__ int dead_s;
+    const int H = p.H, B = p.B, T = p.T, H4 = 4 * p.H;
+    const int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
+    const int j0 = jt * 64, b0 = btile * 32, njt = H / 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kq = wave >> 1, js = wave & 1;
+    const size_t Bp = (size_t)((B + 63) & ~63);
+    unsigned *myctr = ctl.ctr + ((size_t)dir * ctl.nbt + btile) * 32;
+    if (tid == 0) dead_s = 0;
+
+    bf16x8 fb[KS];
+    {
+        const __bf16 *bp = p.whhT + (size_t)dir * H * H4 +
+                           (((size_t)(2 * jt + js) * KS4 + (size_t)kq * KS) * 64 + lane) * 8;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) fb[k] = *reinterpret_cast<const bf16x8 *>(bp + k * 512);
+    }
+    const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(
+        p.dgbuf, 0, (int)(2 * 2 * Bp * H4 * 2), 0x00020000);
+
+    float dcarry[4];
+    int len[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int b = b0 + e * 8 + wave;
+        dcarry[e] = 0.f;
+        len[e] = b < B ? p.lens[b] : 0;
+    }
+    const int col = lane, j = j0 + col;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;
+        float pg[4][4], pcs[4], pcp[4], pdy[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = b0 + e * 8 + wave;
+            const int bc = b < B ? b : B - 1;
+            const size_t gsave = ((((size_t)t * 2 + dir) * B + bc) * 4) * H + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pg[e][g] = p.gates[gsave + (size_t)g * H];
+            pcs[e] = p.csave[(((size_t)t * 2 + dir) * B + bc) * H + j];
+            const int tp = dir == 0 ? t - 1 : t + 1;
+            const int tpc = tp < 0 ? 0 : (tp >= T ? T - 1 : tp);
+            const float cpv = p.csave[(((size_t)tpc * 2 + dir) * B + bc) * H + j];
+            pcp[e] = (tp >= 0 && tp < len[e]) ? cpv : 0.f;
+            pdy[e] = p.dy[(((size_t)t * B + bc) * 2 + dir) * H + j];
+        }
+        if (step > 0 && tid == 0 && !dead_s) {
+            if (!team_wait(myctr, (unsigned)(njt * step), ctl.spin_limit, ctl.err)) dead_s = 1;
+        }
+        __syncthreads();
+        // ---- dgates_{prev step} rows of this batch tile, all 4H columns: 4*KS KiB, sc1 loads only
+        {
+            constexpr int CH = KS4 * 64, NI = (CH + 511) / 512;
+            const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H4 +
+                                              (size_t)btile * KS4 * 512) * 2);
+            u32x4 tmp[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int ch = i * 512 + tid;
+                if (ch < CH) tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(dres, base + ch * 16, 0, ASR_SC1);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int ch = i * 512 + tid;
+                if (ch < CH) reinterpret_cast<u32x4 *>(a_lds)[ch] = tmp[i];
+            }
+        }
+        __syncthreads();
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const bf16x8 *al = reinterpret_cast<const bf16x8 *>(a_lds) + (size_t)kq * KS * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[k * 64], fb[k], acc, 0, 0, 0);
+            const int c32 = lane & 31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                part[kq][row][js * 32 + c32] = acc[i];
+            }
+        }
+        __syncthreads();
+        const bool dead = dead_s != 0;
+        float od[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = e * 8 + wave;
+            if (t < len[e]) {
+                const float dh = pdy[e] + (part[0][row][col] + part[1][row][col]) +
+                                 (part[2][row][col] + part[3][row][col]);
+                float dcout;
+                lstm_cell_bwd(pg[e], pcs[e], pcp[e], dh, dcarry[e], od[e], dcout);
+                dcarry[e] = dcout;
+                if (dead) od[e][0] = od[e][1] = od[e][2] = od[e][3] = __builtin_nanf("");
+            } else {
+                od[e][0] = od[e][1] = od[e][2] = od[e][3] = 0.f;
+                dcarry[e] = 0.f;
+            }
+            const int slot = ((col >> 4) * 64 + row + 32 * ((col >> 3) & 1)) * 8 + (col & 7);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dg_lds[g * 2048 + slot] = (__bf16)od[e][g];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int bi = wave * 2 + r, g = bi >> 2, kk = bi & 3;
+            const u32x4 v = reinterpret_cast<const u32x4 *>(dg_lds)[bi * 64 + lane];
+            const unsigned off = (unsigned)(((((size_t)((step + 1) & 1) * 2 + dir) * Bp * H4) +
+                                             ((size_t)btile * KS4 + g * KS + 4 * jt + kk) * 512 + lane * 8) * 2);
+            __builtin_amdgcn_raw_buffer_store_b128(v, dres, off, 0, ASR_SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(myctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = b0 + e * 8 + wave;
+            if (b < B) {
+                __bf16 *dgo = p.dgates + (((size_t)t * B + b) * 2 + dir) * H4 + j;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dgo[(size_t)g * H] = (__bf16)od[e][g];
+            }
+        }
+    }
+}
+
 __global__ void zero_bytes_kernel(uint32_t *p, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -378,15 +714,58 @@ inline void zero_async(void *p, size_t bytes, hipStream_t s) {
     hipLaunchKernelGGL(zero_bytes_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t *)p, n);
 }
 
+inline int64_t ctl_bytes(int B) { return ((int64_t)2 * ((B + 31) / 32) * 128 + 256 + 255) / 256 * 256; }
+
+// persistent path on unless ASR_LSTM_PERSIST=0 (A/B switch for tests and profiling)
+inline bool persist_enabled() {
+    const char *e = getenv("ASR_LSTM_PERSIST");
+    return !(e && e[0] == '0');
+}
+
+inline int cu_count() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+}
+
+// Launch a persistent kernel over all batch tiles, at most one workgroup per CU
+// per launch (every team of a launch must be resident).  Returns false if the
+// shape cannot run persistently (caller falls back to one launch per step).
+template <typename P>
+bool launch_persist(void (*kern)(P, LstmTeamCtl), const P &p, int B, int H, size_t lds_need,
+                    unsigned *ctl_words, hipStream_t s) {
+    const int njt = H / 64, nbt = (B + 31) / 32;
+    const int cus = cu_count();
+    if ((H % 64) != 0 || njt < 1 || cus < 2 * njt || lds_need > 160 * 1024) return false;
+    const size_t lds = lds_need > 84 * 1024 ? lds_need : 84 * 1024;     // > half the LDS: 1 workgroup per CU
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return false;
+    const int max_bt = cus / (2 * njt);
+    LstmTeamCtl ctl;
+    ctl.ctr = ctl_words + 64;
+    ctl.err = ctl_words;
+    ctl.spin_limit = 1u << 18;
+    ctl.nbt = nbt;
+    for (int bt0 = 0; bt0 < nbt; bt0 += max_bt) {
+        ctl.bt0 = bt0;
+        const int n = nbt - bt0 < max_bt ? nbt - bt0 : max_bt;
+        hipLaunchKernelGGL(kern, dim3(njt, n, 2), dim3(512), lds, s, p, ctl);
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" int64_t asr_lstm_workspace_bytes(int B, int H) {
     if (B < 0 || H < 0) return -1;
     // forward: hbuf bf16 [2][2][Bp][H] + cbuf f32 [2][B][H] + packed W_hh
     // backward: dgbuf bf16 [2][2][Bp][4H] + dcbuf f32 [2][B][H] + packed W_hhᵀ (larger)
+    // + team counters of the persistent kernels: [2 dir][ceil(B/32)] x 128 B and a timeout word
     const int64_t Bp = (B + 63) / 64 * 64;
     return (int64_t)2 * 2 * Bp * 4 * H * 2 + (int64_t)2 * B * H * 4 +
-           (int64_t)2 * 4 * H * H * 2 + 256;
+           (int64_t)2 * 4 * H * H * 2 + 256 + ctl_bytes(B);
 }
 
 extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
@@ -419,9 +798,20 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
     // [2 dir x 4 gates] matrices of H x H (rows = hidden unit, cols = k)
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
                        (const __bf16 *)whh_bf16, wpack, 8, H, H, 0);
-    // 64-row batch tiles once the grid still fills the chip, else 32-row tiles
-    // 64-row tiles (bt = 2) halve the W_hh re-reads but were measured SLOWER (13.7 vs
-    // 11.4 us at B=512): the step is latency-bound per workgroup, not fetch-bound
+    if (persist_enabled()) {
+        unsigned *ctl_words = (unsigned *)((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B));
+        zero_async(ctl_words, (size_t)ctl_bytes(B), s);
+        void (*pk)(LstmFwdParams, LstmTeamCtl) = nullptr;
+#define ASR_PICK(KSV) if (H == 16 * KSV) pk = lstm_fwd_persist_kernel<KSV>;
+        ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32) ASR_PICK(48)
+#undef ASR_PICK
+        if (pk && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + ASR_GLDS_BYTES + 4096,
+                                 ctl_words, s))
+            return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
+    // one launch per step.  64-row tiles (bt = 2) halve the W_hh re-reads but were
+    // measured SLOWER (13.7 vs 11.4 us at B=512): the step is latency-bound per
+    // workgroup, not fetch-bound
     const int bt = 1;
     const dim3 grid(H / 32, (B + 32 * bt - 1) / (32 * bt), 2);
     void (*kern)(LstmFwdParams) = nullptr;
@@ -463,8 +853,17 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
     // whhT_bf16 is [2][H][4H] row-major: rows = hidden unit j, cols = k over 4H
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
                        (const __bf16 *)whhT_bf16, wpack, 2, H, 4 * H, 0);
-    // 64-row tiles (bt = 2) halve the W_hh re-reads but were measured SLOWER (13.7 vs
-    // 11.4 us at B=512): the step is latency-bound per workgroup, not fetch-bound
+    if (persist_enabled()) {
+        unsigned *ctl_words = (unsigned *)((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B));
+        zero_async(ctl_words, (size_t)ctl_bytes(B), s);
+        void (*pk)(LstmBwdParams, LstmTeamCtl) = nullptr;
+#define ASR_PICK(KSV) if (H == 16 * KSV) pk = lstm_bwd_persist_kernel<KSV>;
+        ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24)
+#undef ASR_PICK
+        if (pk && launch_persist(pk, p, B, H, (size_t)(H / 4) * 1024 + ASR_GLDS_BYTES + 16384,
+                                 ctl_words, s))
+            return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
     const int bt = 1;
     const dim3 grid(H / 32, (B + 32 * bt - 1) / (32 * bt), 2);
     void (*kern)(LstmBwdParams) = nullptr;

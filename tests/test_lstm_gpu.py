@@ -57,3 +57,50 @@ def test_bilstm_matches_packed_torch_lstm(T, B, F, H, lens):
     close(xg.grad, dx_ref, 'dx', 5e-2)
     for p, w in zip(rnn_g.parameters(), dw_ref):
         close(p.grad, w, 'dw', 5e-2)
+
+
+def _run_native(gx, whh, lens, dy, persist):
+    import os
+    from att_speech import _native
+    os.environ['ASR_LSTM_PERSIST'] = '1' if persist else '0'
+    try:
+        y, ybf, gates, csave = _native.lstm_bidir_fwd(gx, whh, lens)
+        whhT = whh.view(2, -1, whh.size(-1)).transpose(1, 2).contiguous()
+        dg = _native.lstm_bidir_bwd(dy, whhT, lens, gates, csave)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop('ASR_LSTM_PERSIST', None)
+    return y, ybf, gates, csave, dg
+
+
+@pytest.mark.parametrize('T,B,H,reps', [
+    (23, 7, 64, 1),            # one workgroup per team, ragged batch tile
+    (61, 45, 128, 1),          # two-workgroup teams
+    (150, 96, 320, 1),         # five-workgroup teams (the encoder's hidden size)
+    (334, 512, 320, 3),        # bench shape: 160 workgroups, every hand-off cross-XCD
+    (40, 900, 320, 1),         # more batch tiles than CUs allow in one launch
+    (30, 64, 512, 1),          # backward falls back to one launch per step (LDS)
+])
+def test_persistent_recurrence_is_bitwise_the_per_step_one(T, B, H, reps):
+    """The persistent kernels (teams handing h_t / dgates_t over through L2 inside
+    one launch) do the same arithmetic in the same order as the one-launch-per-
+    step kernels, so every output must agree bit for bit; one stale or torn
+    hand-off changes bits.  Repeated at the bench shape with uneven lengths."""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(T * 31 + B)
+    lens = torch.randint(1, T + 1, (B,), generator=g).sort(descending=True)[0]
+    lens[0] = T
+    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 1.5).to(dev)
+    whh = (torch.randn(2, 4 * H, H, generator=g) * (1.0 / H ** 0.5)).to(dev, torch.bfloat16)
+    dy = torch.randn(T, B, 2, H, generator=g).to(dev)
+    lens_d = lens.to(dev, torch.int32)
+    ref = _run_native(gx, whh, lens_d, dy, persist=False)
+    act = (torch.arange(T)[:, None] < lens[None, :]).to(dev)           # [T,B]
+    for _ in range(reps):
+        out = _run_native(gx, whh, lens_d, dy, persist=True)
+        for name, a, b in zip(('y', 'y_bf16', 'gates', 'csave', 'dgates'), out, ref):
+            if name == 'gates':                                         # [T,2,B,4,H]: defined on active frames
+                m = act[:, None, :, None, None].expand_as(a)
+                a, b = a[m], b[m]
+            assert not torch.isnan(a.float()).any(), name
+            assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
