@@ -419,6 +419,15 @@ __device__ __forceinline__ bool team_wait(unsigned *ctr, unsigned target, unsign
     return false;
 }
 
+#ifdef ASR_LSTM_STAMPS
+#define PSTAMP_DECL unsigned long long pst[6] = {0, 0, 0, 0, 0, 0}, plast = __builtin_amdgcn_s_memtime()
+#define PSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                       pst[i] += now_ - plast; plast = now_; } while (0)
+#else
+#define PSTAMP_DECL do {} while (0)
+#define PSTAMP(i) do {} while (0)
+#endif
+
 struct LstmTeamCtl {
     unsigned *ctr;          // [2 dir][nbt] counters, 32 words (128 B) apart, zeroed per call
     unsigned *err;          // timeout word
@@ -455,51 +464,92 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         p.hbuf, 0, (int)(2 * 2 * Bp * H * 2), 0x00020000);
 
     // the thread's four (row, col) elements: row = e*8 + wave, col = lane
+    const int col = lane, j = j0 + col;
     float c[4];
     __bf16 hq[4];
     int len[4];
+    size_t gxrow[4];            // offset of (b, dir, gate 0, j) inside one frame of gx
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int b = b0 + e * 8 + wave;
+        const int bc = b < B ? b : B - 1;
         c[e] = 0.f;
         hq[e] = (__bf16)0.f;
         len[e] = b < B ? p.lens[b] : 0;
+        gxrow[e] = ((size_t)bc * 2 + dir) * 4 * H + j;
     }
-    const int col = lane, j = j0 + col;
+    const size_t gxframe = (size_t)B * 2 * 4 * H;
 
-    for (int step = 0; step < T; ++step) {
-        const int t = dir == 0 ? step : T - 1 - step;
-        float pgx[4][4];
+    // Software pipeline: the x·W_ih terms of step s+1 are fetched during step s
+    // (behind the hand-off tile in the wave's in-order vmcnt queue, never in
+    // front of the team poll); the outputs nobody inside the launch reads are
+    // stored after the team signal, under the hand-off latency.
+    float pgx[4][4];
+    {
+        const int t0 = dir == 0 ? 0 : T - 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pgx[e][g] = p.gx[(size_t)t0 * gxframe + gxrow[e] + (size_t)g * H];
+    }
+    float sog[4][4], soh[4], sc[4];
+    bool sact[4];
+    int st = 0;
+    auto bulk_store = [&]() {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int b = b0 + e * 8 + wave;
-            const int bc = b < B ? b : B - 1;
-            const float *gxp = p.gx + (((size_t)t * B + bc) * 2 + dir) * 4 * H + j;
+            if (b < B) {
+                p.y[(((size_t)st * B + b) * 2 + dir) * H + j] = soh[e];
+                p.ybf[(((size_t)dir * (T + 2) + st + 1) * B + b) * H + j] = (__bf16)soh[e];
+                p.csave[(((size_t)st * 2 + dir) * B + b) * H + j] = sc[e];
+                if (sact[e]) {
+                    const size_t gsave = ((((size_t)st * 2 + dir) * B + b) * 4) * H + j;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pgx[e][g] = gxp[g * H];
+                    for (int g = 0; g < 4; ++g) p.gates[gsave + (size_t)g * H] = sog[e][g];
+                }
+            }
         }
+    };
+
+    PSTAMP_DECL;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? step : T - 1 - step;
         if (step > 0 && tid == 0 && !dead_s) {
             if (!team_wait(myctr, (unsigned)(njt * step), ctl.spin_limit, ctl.err)) dead_s = 1;
         }
+        PSTAMP(0);
         __syncthreads();
         // ---- h_{t-1} tile of the whole team: KS KiB, sc1 loads only
+        constexpr int CH = KS * 64, NI = (CH + 511) / 512;
+        u32x4 tmp[NI];
         {
-            constexpr int CH = KS * 64, NI = (CH + 511) / 512;
             const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H +
                                               (size_t)btile * KS * 512) * 2);
-            u32x4 tmp[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int ch = i * 512 + tid;
-                if (ch < CH) tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(hres, base + ch * 16, 0, ASR_SC1);
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int ch = i * 512 + tid;
-                if (ch < CH) reinterpret_cast<u32x4 *>(a_lds)[ch] = tmp[i];
+                const int ch = i * 512 + tid;       // lanes past the tile re-read its last chunk
+                tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(hres, base + (ch < CH ? ch : CH - 1) * 16,
+                                                               0, ASR_SC1);
             }
         }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int ch = i * 512 + tid;
+            if (ch < CH) reinterpret_cast<u32x4 *>(a_lds)[ch] = tmp[i];
+        }
         __syncthreads();
+        PSTAMP(1);
+        float ngx[4][4];
+        {
+            const int sn = step + 1 < T ? step + 1 : step;
+            const int tn = dir == 0 ? sn : T - 1 - sn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    ngx[e][g] = p.gx[(size_t)tn * gxframe + gxrow[e] + (size_t)g * H];
+        }
         {
             f32x16 acc;
 #pragma unroll
@@ -516,24 +566,25 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
             }
         }
         __syncthreads();
+        PSTAMP(2);
         const bool dead = dead_s != 0;
-        float og[4][4], oh[4];
-        bool act[4];
+        st = t;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = e * 8 + wave;
-            act[e] = t < len[e];
-            if (act[e]) {
+            sact[e] = t < len[e];
+            if (sact[e]) {
                 float pre[4], cn;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pre[g] = g_lds[g][row][col] + pgx[e][g];
-                lstm_cell_fwd(pre, c[e], og[e], cn, oh[e]);
+                lstm_cell_fwd(pre, c[e], sog[e], cn, soh[e]);
                 c[e] = cn;
-                if (dead) oh[e] = __builtin_nanf("");
-                hq[e] = (__bf16)oh[e];
+                if (dead) soh[e] = __builtin_nanf("");
+                hq[e] = (__bf16)soh[e];
             } else {
-                oh[e] = 0.f;
+                soh[e] = 0.f;
             }
+            sc[e] = c[e];
             h_lds[(((col >> 4) * 64) + row + 32 * ((col >> 3) & 1)) * 8 + (col & 7)] = hq[e];
         }
         __syncthreads();
@@ -543,25 +594,23 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
                                              ((size_t)btile * KS + 4 * jt + wave) * 512 + lane * 8) * 2);
             __builtin_amdgcn_raw_buffer_store_b128(v, hres, off, 0, ASR_SC1);
         }
+        PSTAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        PSTAMP(4);
         if (tid == 0) __hip_atomic_fetch_add(myctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- outputs nobody inside this launch reads: plain stores, after the signal
+        bulk_store();       // outputs nobody inside this launch reads: after the signal
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int b = b0 + e * 8 + wave;
-            if (b < B) {
-                p.y[(((size_t)t * B + b) * 2 + dir) * H + j] = oh[e];
-                p.ybf[(((size_t)dir * (T + 2) + t + 1) * B + b) * H + j] = (__bf16)oh[e];
-                p.csave[(((size_t)t * 2 + dir) * B + b) * H + j] = c[e];
-                if (act[e]) {
-                    const size_t gsave = ((((size_t)t * 2 + dir) * B + b) * 4) * H + j;
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) p.gates[gsave + (size_t)g * H] = og[e][g];
-                }
-            }
-        }
+            for (int g = 0; g < 4; ++g) pgx[e][g] = ngx[e][g];
+        PSTAMP(5);
     }
+#ifdef ASR_LSTM_STAMPS
+    __syncthreads();
+    if (tid == 0 && b0 < B)
+        for (int i = 0; i < 6; ++i) p.y[(((size_t)0 * B + b0) * 2 + dir) * H + j0 + i] = (float)pst[i] / T;
+#endif
 }
 
 template <int KS>
@@ -591,55 +640,88 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
     const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(
         p.dgbuf, 0, (int)(2 * 2 * Bp * H4 * 2), 0x00020000);
 
+    const int col = lane, j = j0 + col;
     float dcarry[4];
-    int len[4];
+    int len[4], bcl[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int b = b0 + e * 8 + wave;
         dcarry[e] = 0.f;
         len[e] = b < B ? p.lens[b] : 0;
+        bcl[e] = b < B ? b : B - 1;
     }
-    const int col = lane, j = j0 + col;
 
-    for (int step = 0; step < T; ++step) {
-        const int t = dir == 0 ? T - 1 - step : step;
-        float pg[4][4], pcs[4], pcp[4], pdy[4];
+    // operands of the cell backward at frame t: saved gates, dy, and the cell
+    // state the step started from (c of the neighbouring frame, raw); c_t itself
+    // is the neighbour value fetched one step earlier
+    struct Pre { float g[4][4], cp[4], dy[4]; };
+    auto fetch = [&](int t, Pre &q) {
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        const int tpc = tp < 0 ? 0 : (tp >= T ? T - 1 : tp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const size_t gsave = ((((size_t)t * 2 + dir) * B + bcl[e]) * 4) * H + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) q.g[e][g] = p.gates[gsave + (size_t)g * H];
+            q.cp[e] = p.csave[(((size_t)tpc * 2 + dir) * B + bcl[e]) * H + j];
+            q.dy[e] = p.dy[(((size_t)t * B + bcl[e]) * 2 + dir) * H + j];
+        }
+    };
+    Pre cur;
+    float pcs[4];
+    {
+        const int t0 = dir == 0 ? T - 1 : 0;
+        fetch(t0, cur);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pcs[e] = p.csave[(((size_t)t0 * 2 + dir) * B + bcl[e]) * H + j];
+    }
+    __bf16 sod[4][4];
+    int st = 0;
+    auto bulk_store = [&]() {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int b = b0 + e * 8 + wave;
-            const int bc = b < B ? b : B - 1;
-            const size_t gsave = ((((size_t)t * 2 + dir) * B + bc) * 4) * H + j;
+            if (b < B) {
+                __bf16 *dgo = p.dgates + (((size_t)st * B + b) * 2 + dir) * H4 + j;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pg[e][g] = p.gates[gsave + (size_t)g * H];
-            pcs[e] = p.csave[(((size_t)t * 2 + dir) * B + bc) * H + j];
-            const int tp = dir == 0 ? t - 1 : t + 1;
-            const int tpc = tp < 0 ? 0 : (tp >= T ? T - 1 : tp);
-            const float cpv = p.csave[(((size_t)tpc * 2 + dir) * B + bc) * H + j];
-            pcp[e] = (tp >= 0 && tp < len[e]) ? cpv : 0.f;
-            pdy[e] = p.dy[(((size_t)t * B + bc) * 2 + dir) * H + j];
+                for (int g = 0; g < 4; ++g) dgo[(size_t)g * H] = sod[e][g];
+            }
         }
+    };
+
+    PSTAMP_DECL;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;
         if (step > 0 && tid == 0 && !dead_s) {
             if (!team_wait(myctr, (unsigned)(njt * step), ctl.spin_limit, ctl.err)) dead_s = 1;
         }
+        PSTAMP(0);
         __syncthreads();
         // ---- dgates_{prev step} rows of this batch tile, all 4H columns: 4*KS KiB, sc1 loads only
+        constexpr int CH = KS4 * 64, NI = (CH + 511) / 512;
+        u32x4 tmp[NI];
         {
-            constexpr int CH = KS4 * 64, NI = (CH + 511) / 512;
             const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H4 +
                                               (size_t)btile * KS4 * 512) * 2);
-            u32x4 tmp[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int ch = i * 512 + tid;
-                if (ch < CH) tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(dres, base + ch * 16, 0, ASR_SC1);
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int ch = i * 512 + tid;
-                if (ch < CH) reinterpret_cast<u32x4 *>(a_lds)[ch] = tmp[i];
+                tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(dres, base + (ch < CH ? ch : CH - 1) * 16,
+                                                               0, ASR_SC1);
             }
         }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int ch = i * 512 + tid;
+            if (ch < CH) reinterpret_cast<u32x4 *>(a_lds)[ch] = tmp[i];
+        }
         __syncthreads();
+        PSTAMP(1);
+        Pre nxt;
+        {
+            const int sn = step + 1 < T ? step + 1 : step;
+            fetch(dir == 0 ? T - 1 - sn : sn, nxt);
+        }
         {
             f32x16 acc;
 #pragma unroll
@@ -656,25 +738,34 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
             }
         }
         __syncthreads();
+        PSTAMP(2);
         const bool dead = dead_s != 0;
-        float od[4][4];
+        st = t;
+        const int tp = dir == 0 ? t - 1 : t + 1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = e * 8 + wave;
+            float od[4];
             if (t < len[e]) {
-                const float dh = pdy[e] + (part[0][row][col] + part[1][row][col]) +
+                const float dh = cur.dy[e] + (part[0][row][col] + part[1][row][col]) +
                                  (part[2][row][col] + part[3][row][col]);
+                const float cp = (tp >= 0 && tp < len[e]) ? cur.cp[e] : 0.f;
                 float dcout;
-                lstm_cell_bwd(pg[e], pcs[e], pcp[e], dh, dcarry[e], od[e], dcout);
+                lstm_cell_bwd(cur.g[e], pcs[e], cp, dh, dcarry[e], od, dcout);
                 dcarry[e] = dcout;
-                if (dead) od[e][0] = od[e][1] = od[e][2] = od[e][3] = __builtin_nanf("");
+                if (dead) od[0] = od[1] = od[2] = od[3] = __builtin_nanf("");
             } else {
-                od[e][0] = od[e][1] = od[e][2] = od[e][3] = 0.f;
+                // no gradient reaches a padding frame; the carried state gradient restarts from zero
+                od[0] = od[1] = od[2] = od[3] = 0.f;
                 dcarry[e] = 0.f;
             }
             const int slot = ((col >> 4) * 64 + row + 32 * ((col >> 3) & 1)) * 8 + (col & 7);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) dg_lds[g * 2048 + slot] = (__bf16)od[e][g];
+            for (int g = 0; g < 4; ++g) {
+                sod[e][g] = (__bf16)od[g];
+                dg_lds[g * 2048 + slot] = sod[e][g];
+            }
+            pcs[e] = cur.cp[e];         // c of the frame the next step visits
         }
         __syncthreads();
 #pragma unroll
@@ -685,19 +776,21 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
                                              ((size_t)btile * KS4 + g * KS + 4 * jt + kk) * 512 + lane * 8) * 2);
             __builtin_amdgcn_raw_buffer_store_b128(v, dres, off, 0, ASR_SC1);
         }
+        PSTAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        PSTAMP(4);
         if (tid == 0) __hip_atomic_fetch_add(myctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int b = b0 + e * 8 + wave;
-            if (b < B) {
-                __bf16 *dgo = p.dgates + (((size_t)t * B + b) * 2 + dir) * H4 + j;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) dgo[(size_t)g * H] = (__bf16)od[e][g];
-            }
-        }
+        bulk_store();
+        cur = nxt;
+        PSTAMP(5);
     }
+#ifdef ASR_LSTM_STAMPS
+    __syncthreads();
+    if (tid == 0 && b0 < B)
+        for (int i = 0; i < 6; ++i)
+            p.dgates[(((size_t)0 * B + b0) * 2 + dir) * H4 + j0 + i] = (__bf16)((float)pst[i] / T / 16.f);
+#endif
 }
 
 __global__ void zero_bytes_kernel(uint32_t *p, size_t n) {
@@ -803,7 +896,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
         zero_async(ctl_words, (size_t)ctl_bytes(B), s);
         void (*pk)(LstmFwdParams, LstmTeamCtl) = nullptr;
 #define ASR_PICK(KSV) if (H == 16 * KSV) pk = lstm_fwd_persist_kernel<KSV>;
-        ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32) ASR_PICK(48)
+        ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32)   // 48: W_hh slice spills
 #undef ASR_PICK
         if (pk && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + ASR_GLDS_BYTES + 4096,
                                  ctl_words, s))
