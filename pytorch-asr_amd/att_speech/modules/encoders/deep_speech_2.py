@@ -19,6 +19,8 @@ class DeepSpeech2(BaseEncoder):
                  rnn_type=nn.LSTM, rnn_dropout=0.0, rnn_residual=False,
                  rnn_normalization='batch_norm', rnn_subsample=None, **kwargs):
         super(DeepSpeech2, self).__init__(**kwargs)
+        import os
+        self.conv_bf16 = os.environ.get('ASR_CONV_BF16', '1') != '0'
         if isinstance(rnn_type, str):
             rnn_type = {'LSTM': nn.LSTM, 'GRU': nn.GRU}[rnn_type.split('.')[-1]]
         self.makeConv(sample_batch, conv_strides, conv_kernel_sizes,
@@ -79,11 +81,27 @@ class DeepSpeech2(BaseEncoder):
             rnns.append(('{}'.format(i + 1), rnn))
         self.rnns = SequentialWithOptionalAttributes(OrderedDict(rnns))
 
+    def _conv_forward(self, features):
+        """conv stack; on the GPU the 32->32 channel convolution (97 % of the
+        stack's flops) takes bf16 operands with fp32 accumulation, like the
+        LSTM GEMMs (BASELINE config 2: bf16); BatchNorm statistics, Hardtanh and
+        the one-channel first convolution stay fp32."""
+        if not (features.is_cuda and self.conv_bf16 and len(self.conv) == 6
+                and isinstance(self.conv[3], nn.Conv2d)):
+            return self.conv(features)
+        x = self.conv[2](self.conv[1](self.conv[0](features)))
+        c2 = self.conv[3]
+        x = nn.functional.conv2d(
+            x.to(torch.bfloat16), c2.weight.to(torch.bfloat16),
+            None if c2.bias is None else c2.bias.to(torch.bfloat16),
+            c2.stride, c2.padding, c2.dilation, c2.groups)
+        return self.conv[5](self.conv[4](x.float()))
+
     def forward(self, features, features_lengths, spkids, ivectors=None,
                 characteristic_vectors=None, **kwargs):
         # bs x t x f x c -> bs x c x t x f
         features = features.permute(0, 3, 1, 2)
-        features = self.conv(features)
+        features = self._conv_forward(features)
         batch_size, _, num_timestp, _ = features.size()
         # bs x c x t x f -> t x bs x (c x f)
         features = features.permute(2, 0, 1, 3).contiguous()
