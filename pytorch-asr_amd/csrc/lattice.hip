@@ -7,6 +7,7 @@
 // buffered, one s_barrier per frame); the per-frame gradient row is
 // accumulated in LDS (ds_add_f32) and streamed out coalesced, so every
 // [t,b,:] row of the dense gradient is written exactly once.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -28,6 +29,7 @@ struct FwbwParams {
     float neg_inf;
     float *logZ, *grad, *logZ_bwd;
     float *alphas;  // [T,B,N]
+    int *skip;      // [B] or null: utterances already done by the band kernel
 };
 
 // KR > 0: every thread owns ONE state (N <= blockDim) and keeps its <= KR
@@ -546,6 +548,7 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
     extern __shared__ float smem[];
     typedef unsigned int u32;
     const int b = blockIdx.x;
+    if (p.skip && p.skip[b]) return;                  // done by lattice_fwbw_band_kernel
     const int H = blockDim.x >> 1;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >= (unsigned)H ? 1 : 0);
     const int n = threadIdx.x - grp * H;
@@ -947,6 +950,399 @@ struct FwdParams {
     uint16_t *bp;  // [T,B,N] arg-max arc slot, viterbi only
 };
 
+// ---------------------------------------------------------------------------
+// BAND lattices: state-labelled graphs whose in-arcs come from states
+// {n, n-1, n-2} and whose out-arcs go to {n, n+1, n+2} — every CTC numerator
+// lattice of the reference (compose(decoding_fst, chain), fst_utils.py:603-613:
+// blank_0, label_0, blank_1, ... with self loops, next-state arcs and the
+// skip-the-blank arc).  For these the scan needs no LDS exchange at all:
+//   * ONE wave per chain: wave 0 runs alpha, wave 1 runs beta (meet in the
+//     middle as above); a lane keeps S consecutive states in registers and gets
+//     the two neighbouring states of the next/previous lane with DPP wave
+//     shifts, so there is no barrier and no LDS round trip on the recurrence;
+//   * the log-prob row of a frame is loaded ONCE per chain (lane c holds class
+//     c, C <= 64) D frames ahead and the per-state emissions are gathered from
+//     it with ds_bpermute;
+//   * posteriors are summed per class without atomics: the slots whose states
+//     all carry one label (the blanks) are reduced with one DPP sum, every
+//     other class sums its <= 16 states through a gather list built once per
+//     utterance.
+// The two waves only meet at the phase boundary (alpha_m / beta_m exchange ->
+// logZ).  Graphs that are not bands (or N > 64*S, C > 64, a class with more
+// than 16 states) leave skip[b] = 0 and are handled by the kernels above.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_shr1(float v, float fill) {     // lane i <- lane i-1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        __builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_shl1(float v, float fill) {     // lane i <- lane i+1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        __builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+// log2(2^x0 + 2^x1 + 2^x2): the largest term contributes exactly 1, so two
+// v_exp_f32 (quarter rate) instead of three, for three full-rate min/med/max
+__device__ __forceinline__ float lse3_2(float x0, float x1, float x2) {
+    const float m = __builtin_fmaxf(__builtin_fmaxf(x0, x1), x2);
+    const float lo = __builtin_fminf(__builtin_fminf(x0, x1), x2);
+    const float mid = __builtin_amdgcn_fmed3f(x0, x1, x2);
+    const float s = 1.f + __builtin_amdgcn_exp2f(mid - m) + __builtin_amdgcn_exp2f(lo - m);
+    return m + __builtin_amdgcn_logf(s);
+}
+
+#define BAND_LIST 16
+
+template <int S, int D>
+__global__ __launch_bounds__(128) void lattice_fwbw_band_kernel(FwbwParams p) {
+    typedef unsigned int u32;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    static_assert(S == 4, "ws rows are moved as one 16-byte access per lane");
+    __shared__ float xch[2][64 * S];                   // alpha_m | beta_m
+    __shared__ __attribute__((aligned(16))) float gbuf[2][64 * S + 4];   // posteriors per chain, [64*S] stays 0
+    __shared__ int labtab[64 * S];
+    __shared__ unsigned short lists[64][2][BAND_LIST];
+    __shared__ int lcnt[64][2];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const bool isB = __builtin_amdgcn_readfirstlane(tid >> 6) != 0;
+    const int N = p.N, C = p.C;
+    const int g = (p.Bg == 1) ? 0 : b;
+    const int Kin = p.Kin, Kout = p.Kout;
+    const int32_t *src_in = p.src_in + (size_t)g * N * Kin;
+    const int32_t *il_in = p.il_in + (size_t)g * N * Kin;
+    const float *w_in = p.w_in + (size_t)g * N * Kin;
+    const int32_t *dst_out = p.dst_out + (size_t)g * N * Kout;
+    const float *w_out = p.w_out + (size_t)g * N * Kout;
+    const float *term = p.term + (size_t)g * N;
+    const float half_inf = p.neg_inf * 0.5f;
+    const float NI2 = p.neg_inf * ASR_L2E;
+
+    // ---- per-lane states n = S*lane + s: band weights, labels, structure check
+    int lab[S];
+    float wb[S][3], term2[S];
+    bool dead[S];
+    bool ok = true;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int n = lane * S + s;
+        const bool valid = n < N;
+        lab[s] = valid ? il_in[(size_t)n * Kin] : 0;
+        if (valid && (lab[s] < 0 || lab[s] >= C)) ok = false;
+        float wi0 = NI2, wi1 = NI2, wi2 = NI2, wo0 = NI2, wo1 = NI2, wo2 = NI2;
+        if (valid) {
+            for (int k = 0; k < Kin; ++k) {
+                const float w = w_in[(size_t)n * Kin + k];
+                if (w > half_inf) {
+                    const int d = n - src_in[(size_t)n * Kin + k];
+                    const float w2 = w * ASR_L2E;
+                    if (il_in[(size_t)n * Kin + k] != lab[s]) ok = false;
+                    if (d == 0 && wi0 == NI2) wi0 = w2;
+                    else if (d == 1 && wi1 == NI2) wi1 = w2;
+                    else if (d == 2 && wi2 == NI2) wi2 = w2;
+                    else ok = false;
+                }
+            }
+            for (int k = 0; k < Kout; ++k) {
+                const float w = w_out[(size_t)n * Kout + k];
+                if (w > half_inf) {
+                    const int d = dst_out[(size_t)n * Kout + k] - n;
+                    const float w2 = w * ASR_L2E;
+                    if (d == 0 && wo0 == NI2) wo0 = w2;
+                    else if (d == 1 && wo1 == NI2) wo1 = w2;
+                    else if (d == 2 && wo2 == NI2) wo2 = w2;
+                    else ok = false;
+                }
+            }
+        }
+        wb[s][0] = isB ? wo0 : wi0; wb[s][1] = isB ? wo1 : wi1; wb[s][2] = isB ? wo2 : wi2;
+        term2[s] = valid ? fmaxf(term[n], p.neg_inf) * ASR_L2E : NI2;
+        // batch padding / unreachable states (no in-arc, not the start state) never carry mass
+        const bool alive = valid && (n == 0 || wi0 != NI2 || wi1 != NI2 || wi2 != NI2);
+        dead[s] = !alive;
+        labtab[n] = alive ? lab[s] : -1;
+    }
+    // slots whose valid states all share one label are reduced with DPP
+    bool uni[S];
+    int ul[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        ul[s] = __builtin_amdgcn_readfirstlane(lab[s]);
+        const bool same = dead[s] || lab[s] == ul[s];
+        uni[s] = __builtin_amdgcn_read_exec() == __ballot(same);      // wave-uniform
+    }
+    // the uniform slots must share ONE label (the blank); its posterior is one DPP sum per frame
+    int ulab = -1;
+#pragma unroll
+    for (int s = S - 1; s >= 0; --s)
+        if (uni[s]) ulab = ul[s];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+        if (uni[s] && ul[s] != ulab) ok = false;
+    __syncthreads();
+    // per-class gather lists over the remaining states: thread (class, half) scans half the states
+    {
+        const int c = lane, half = isB ? 1 : 0;
+        const int nb = half ? (N + 1) / 2 : 0, ne = half ? N : (N + 1) / 2;
+        int cnt = 0;
+        for (int n = nb; n < ne; ++n) {
+            const bool u = uni[0] ? (n % S) == 0 : false;
+            bool slot_uni = u;
+#pragma unroll
+            for (int q = 1; q < S; ++q) slot_uni = slot_uni || (uni[q] && (n % S) == q);
+            if (!slot_uni && labtab[n] == c) {
+                if (cnt < BAND_LIST) lists[c][half][cnt] = (unsigned short)n;
+                ++cnt;
+            }
+        }
+        lcnt[c][half] = cnt;
+    }
+    __syncthreads();
+    int mycnt = lcnt[lane][0] + lcnt[lane][1];
+    if (lane >= C) mycnt = 0;
+    if (mycnt > BAND_LIST) ok = false;
+    if (!__syncthreads_and(ok)) {
+        if (tid == 0) p.skip[b] = 0;
+        return;
+    }
+    if (tid == 0) p.skip[b] = 1;
+    int maxcnt = mycnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o, 64));
+    maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
+    for (int i = tid; i < 2 * (64 * S + 4); i += 128) (&gbuf[0][0])[i] = 0.f;
+
+    int len = p.lens[b];
+    len = len < 0 ? 0 : (len > p.T ? p.T : len);
+    const size_t tstride = (size_t)p.B * C;
+    float *grad_b = p.grad + (size_t)b * C;
+    for (int t = len; t < p.T; ++t)                  // fst_utils.py:448
+        for (int c = tid; c < C; c += 128) grad_b[(size_t)t * tstride + c] = 0.f;
+
+    // The scan proper, instantiated per chain (ISB) and gather-list length (LN)
+    // so that the loop bodies are single basic blocks with an exact VMEM count
+    // per step (counted vmcnt waits, prefetch distance D steps).
+    auto run = [&](auto isb_c, auto ln_c) {
+        constexpr bool ISB = decltype(isb_c)::value;
+        constexpr int LN = decltype(ln_c)::value;
+        float *const G = gbuf[ISB ? 1 : 0];
+        u32 lidx[LN];             // byte offsets into G; unused entries point at the zero slot
+        {
+            const int c0 = lcnt[lane][0];
+#pragma unroll
+            for (int i = 0; i < LN; ++i) {
+                int n = 64 * S;
+                if (i < mycnt) n = i < c0 ? lists[lane][0][i] : lists[lane][1][i - c0];
+                lidx[i] = (u32)n * 4u;
+            }
+        }
+        const int m = len >> 1, solo = len - 2 * m;
+        // ---- buffers (bounds-checked: masked lanes / steps carry an out-of-range offset)
+        const int Hw = (N + 63) / 64 * 64;           // ws row stride (asr_lattice_fwbw_workspace_bytes)
+        const u32 ts4 = (u32)tstride * 4u, as4 = (u32)p.B * (u32)Hw * 4u;
+        const u32 lp_bytes = (u32)(((size_t)p.T * p.B * C - (size_t)b * C) * 4);
+        const u32 ws_bytes = (u32)(((size_t)(p.T + 2) * p.B * Hw - (size_t)b * Hw) * 4);
+        const __amdgpu_buffer_rsrc_t lpR = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(p.lp) + (size_t)b * C, 0, lp_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t gradR =
+            __builtin_amdgcn_make_buffer_rsrc(grad_b, 0, lp_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wsR = __builtin_amdgcn_make_buffer_rsrc(
+            p.alphas + (size_t)b * Hw, 0, ws_bytes, 0x00020000);
+        const u32 OOB = 0x80000000u;                 // every buffer is < 2^31 bytes (host check)
+        const u32 c4 = lane < C ? (u32)lane * 4u : OOB;            // this lane's class column
+        const u32 wn4 = lane * S < N ? (u32)lane * S * 4u : OOB;   // this lane's ws columns
+
+        // ---- schedule of this chain: n0 steps before the meeting point, n1 after;
+        // step j works on frame f(j) = j (alpha) or len-1-j (beta).  The first
+        // phase is padded at the front, the second at the back, to whole rings.
+        const int n0 = ISB ? m + solo : m, n1 = ISB ? m : m + solo;
+        const int pad0 = (D - n0 % D) % D;
+        auto frame_of = [&](int j) -> int { return ISB ? len - 1 - j : j; };
+        auto row_off = [&](int j) -> u32 {            // lp row of step j
+            const bool in = (j >= 0) & (j < n0 + n1);
+            return in ? c4 + (u32)frame_of(j) * ts4 : OOB;
+        };
+        float R[D];                                   // ring of log-prob rows (raw)
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            R[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lpR, row_off(u - pad0), 0, 0));
+        auto gather = [&](float rowv, float (&em)[S]) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                em[s] = ASR_L2E * __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
+                            lab[s] * 4, __builtin_bit_cast(int, rowv)));
+        };
+
+        float a[S];                                   // alpha_t / beta_{t+1}, log2 units
+#pragma unroll
+        for (int s = 0; s < S; ++s) a[s] = ISB ? term2[s] : ((lane == 0 && s == 0) ? 0.f : NI2);
+
+        // one recurrence step with the emissions em of the step's frame
+        auto advance = [&](const float (&em)[S], float (&out)[S]) {
+            if constexpr (!ISB) {
+                const float p3 = wave_shr1(a[S - 1], NI2), p2 = wave_shr1(a[S - 2], NI2);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float x0 = a[s] + wb[s][0];
+                    const float x1 = (s >= 1 ? a[s >= 1 ? s - 1 : 0] : p3) + wb[s][1];
+                    const float x2 = (s >= 2 ? a[s >= 2 ? s - 2 : 0] : (s == 1 ? p3 : p2)) + wb[s][2];
+                    out[s] = em[s] + lse3_2(x0, x1, x2);
+                }
+            } else {
+                float bt[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) bt[s] = a[s] + em[s];
+                const float q0 = wave_shl1(bt[0], NI2), q1 = wave_shl1(bt[1], NI2);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float y0 = bt[s] + wb[s][0];
+                    const float y1 = (s + 1 < S ? bt[s + 1 < S ? s + 1 : 0] : q0) + wb[s][1];
+                    const float y2 = (s + 2 < S ? bt[s + 2 < S ? s + 2 : 0] : (s + 2 == S ? q0 : q1)) + wb[s][2];
+                    out[s] = lse3_2(y0, y1, y2);
+                }
+            }
+        };
+
+        float em[S];
+        gather(R[0], em);
+        // ================= phase 0: up to the meeting point, keep the states in ws
+        // alpha: slot t <- alpha_{t+1} after frame t;  beta: slot t <- beta_{t+1} before frame t
+        for (int J0 = 0; J0 < n0 + pad0; J0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int j = J0 + u - pad0;
+                const bool act = j >= 0;
+                float nx[S];
+                advance(em, nx);
+                const u32x4 keep = {__builtin_bit_cast(u32, a[0]), __builtin_bit_cast(u32, a[1]),
+                                    __builtin_bit_cast(u32, a[2]), __builtin_bit_cast(u32, a[3])};
+#pragma unroll
+                for (int s = 0; s < S; ++s) a[s] = act ? nx[s] : a[s];
+                const u32x4 fresh = {__builtin_bit_cast(u32, a[0]), __builtin_bit_cast(u32, a[1]),
+                                     __builtin_bit_cast(u32, a[2]), __builtin_bit_cast(u32, a[3])};
+                const u32 slot = (u32)frame_of(j);
+                __builtin_amdgcn_raw_buffer_store_b128(ISB ? keep : fresh, wsR,
+                                                       act ? wn4 + slot * as4 : OOB, 0, 0);
+                R[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                           lpR, row_off(j + D), 0, 0));
+                __builtin_amdgcn_sched_barrier(0);     // keep the refills D steps ahead of their use
+                gather(R[(u + 1) % D], em);
+            }
+        }
+        // ================= meeting point: logZ = LSE_n(alpha_m + beta_m)
+#pragma unroll
+        for (int s = 0; s < S; ++s) xch[ISB ? 1 : 0][lane * S + s] = a[s];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ws rows of this chain are out
+        __syncthreads();
+        float logZ2;
+        {
+            float v[S], mx = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                v[s] = xch[0][lane * S + s] + xch[1][lane * S + s];
+                if (lane * S + s >= N) v[s] = -INFINITY;
+                mx = fmaxf(mx, v[s]);
+            }
+            mx = wave_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) sum += __builtin_amdgcn_exp2f(v[s] - mx);
+            sum = wave_sum(sum);
+            logZ2 = mx + __builtin_amdgcn_logf(sum);
+        }
+        // ================= phase 1: finish the chain; posteriors against the other
+        // chain's stored states (slot t holds alpha_{t+1} for t < m, beta_{t+1} for t >= m)
+        auto ws_off = [&](int k) -> u32 {             // slot read by phase-1 step k
+            return k < n1 ? wn4 + (u32)frame_of(n0 + k) * as4 : OOB;
+        };
+        u32x4 W[D];
+#pragma unroll
+        for (int u = 0; u < D; ++u) W[u] = __builtin_amdgcn_raw_buffer_load_b128(wsR, ws_off(u), 0, 0);
+        float pend[LN];                               // gathered posteriors of the previous step
+        float ptot = 0.f;
+        u32 pgoff = OOB;
+#pragma unroll
+        for (int i = 0; i < LN; ++i) pend[i] = 0.f;
+        auto flush = [&]() {                          // grad row of the previous step
+            float r = lane == ulab ? ptot : 0.f;
+#pragma unroll
+            for (int i = 0; i < LN; ++i) r += pend[i];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), gradR, pgoff, 0, 0);
+        };
+        for (int K0 = 0; K0 < n1; K0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int k = K0 + u;
+                const bool act = k < n1;
+                float nx[S], gam[S];
+                // (bit_cast of the whole vector: __builtin_bit_cast(float, W[u].y) on a vector ELEMENT
+                // reads the vector's first dword with this hipcc)
+                typedef __attribute__((ext_vector_type(4))) float f32x4v;
+                const f32x4v wf = __builtin_bit_cast(f32x4v, W[u]);
+                const float oth[S] = {wf.x, wf.y, wf.z, wf.w};
+                advance(em, nx);
+                // alpha wave: gamma from the NEW alpha_{t+1}; beta wave: from beta_{t+1} before the update
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float mine = ISB ? a[s] : nx[s];
+                    gam[s] = __builtin_amdgcn_exp2f(mine + oth[s] - logZ2);
+                    const bool live = (lane * S + s < N) & act;
+                    gam[s] = live ? gam[s] : 0.f;
+                    a[s] = act ? nx[s] : a[s];
+                }
+                flush();                               // previous step's row (its LDS reads are long back)
+                // stage this step's posteriors: uniform slots -> one DPP sum, the rest -> gather lists
+                // (scalar stores: a float4-typed store and the float-typed gather loads below would
+                // be "no alias" for the compiler and the store gets dropped)
+#pragma unroll
+                for (int s = 0; s < S; ++s) G[lane * S + s] = gam[s];
+#pragma unroll
+                for (int i = 0; i < LN; ++i)
+                    pend[i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(G) + lidx[i]);
+                {
+                    float v = 0.f;
+#pragma unroll
+                    for (int q = 0; q < S; ++q) v += uni[q] ? gam[q] : 0.f;
+                    ptot = dpp_wave_sum(v);
+                }
+                pgoff = act ? c4 + (u32)frame_of(n0 + k) * ts4 : OOB;
+                W[u] = __builtin_amdgcn_raw_buffer_load_b128(wsR, ws_off(k + D), 0, 0);
+                R[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                           lpR, row_off(n0 + k + D), 0, 0));
+                __builtin_amdgcn_sched_barrier(0);
+                gather(R[(u + 1) % D], em);
+            }
+        }
+        flush();
+        // ================= totals
+        {
+            // alpha: logZ = LSE_n(alpha_len + terminal) (fst_utils.py:445); beta: from beta_0 (:476)
+            float mx = -INFINITY, v[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float add = ISB ? ((lane == 0 && s == 0) ? 0.f : NI2) : term2[s];
+                v[s] = lane * S + s < N ? a[s] + add : -INFINITY;
+                mx = fmaxf(mx, v[s]);
+            }
+            mx = wave_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) sum += __builtin_amdgcn_exp2f(v[s] - mx);
+            sum = wave_sum(sum);
+            float *dst = ISB ? p.logZ_bwd : p.logZ;
+            if (lane == 0 && dst) dst[b] = (mx + __builtin_amdgcn_logf(sum)) * ASR_LN2;
+        }
+    };
+    typedef std::integral_constant<bool, false> CA;
+    typedef std::integral_constant<bool, true> CB;
+    typedef std::integral_constant<int, BAND_LIST / 2> L8;
+    typedef std::integral_constant<int, BAND_LIST> L16;
+    if (isB) {
+        if (maxcnt <= BAND_LIST / 2) run(CB(), L8()); else run(CB(), L16());
+    } else {
+        if (maxcnt <= BAND_LIST / 2) run(CA(), L8()); else run(CA(), L16());
+    }
+}
+
+
+
 template <bool VITERBI>
 __global__ void lattice_forward_kernel(FwdParams p) {
     extern __shared__ float smem[];
@@ -1095,6 +1491,7 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     p.N = N; p.Kin = Kin; p.Kout = Kout; p.Bg = Bg; p.neg_inf = neg_inf;
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
+    p.skip = nullptr;
 
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
@@ -1116,6 +1513,16 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
             kern = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 0> : lattice_fwbw_sl_kernel<4, 8, 0>;
         nt = 2 * H;
         lds = lds_sl > lds_mitm ? lds_sl : lds_mitm;
+        // Experimental (ASR_LATTICE_BAND=1): one-wave-per-chain kernel for band lattices.
+        // Correct (same tests) but slower today: 180 us vs 151 us on the B=512 mono
+        // numerator — a single wave per SIMD is issue-bound at ~1240 cycles per step.
+        const char *band_env = getenv("ASR_LATTICE_BAND");
+        if (band_env && band_env[0] == '1' && N <= 256 && C <= 64 && T > 0) {
+            // band lattices (CTC chains) first; it flags the utterances it has done
+            p.skip = (int *)((char *)workspace + (size_t)(T + 2) * B * H * sizeof(float));
+            hipLaunchKernelGGL((lattice_fwbw_band_kernel<4, 8>), dim3(B), dim3(128), 0,
+                               (hipStream_t)stream, p);
+        }
     } else if (N <= 1024 && Kmax <= 4) {
         kern = lattice_fwbw_kernel<4>;
         nt = round_up(N, 64);

@@ -52,7 +52,8 @@ def _worker(rank, world, port, q):
         bucket.zero_()
         _loss(model, x[idx], lens[idx]).backward()
         bucket.all_reduce_sum()
-    q.put((rank, idx, [p.grad.clone() for p in model.parameters()]))
+    # plain numpy through the queue: shared-memory tensors need the sender alive until received
+    q.put((rank, idx, [p.grad.detach().numpy().copy() for p in model.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,7 +80,7 @@ def test_dp_gradients_are_the_sum_over_shards():
     for rank, idx, grads in res:
         assert lens[idx].tolist() == sorted(lens[idx].tolist(), reverse=True)
         for a, b in zip(grads, want):
-            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(torch.from_numpy(a), b, rtol=1e-5, atol=1e-6)
     assert sorted(res[0][1] + res[1][1]) == list(range(6))
 
 

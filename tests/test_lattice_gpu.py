@@ -356,3 +356,17 @@ def test_log_softmax_and_rowmax(oracle_lib):
     np.testing.assert_array_equal(y.cpu().numpy(), a - a.max(-1, keepdims=True))
     mask = np.arange(T)[:, None] < lens[None, :]
     np.testing.assert_allclose(msum.cpu().numpy(), (a.max(-1) * mask).sum(0), rtol=1e-5, atol=1e-5)
+
+
+def test_band_kernel_matches_golden(monkeypatch):
+    """ASR_LATTICE_BAND=1 routes band-structured (CTC chain) lattices through the
+    experimental one-wave-per-chain kernel (csrc/lattice.hip, lattice_fwbw_band_kernel);
+    same golden vectors, same tolerances."""
+    monkeypatch.setenv('ASR_LATTICE_BAND', '1')
+    for name in ('lattice_mono', 'lattice_bigram_s7'):
+        g = golden(name + '.npz')
+        mats = [g['gm%d' % i] for i in range(8)]
+        logZ, grad, zb = run_fwbw(g['lp'], g['lens'], mats, want_bwd=True)
+        np.testing.assert_allclose(logZ, g['fwbw_logZ'], rtol=RTOL_LOSS)
+        np.testing.assert_allclose(grad, g['fwbw_grad'], atol=grad_atol(logZ))
+        assert np.abs(zb - logZ).max() < 1e-3
