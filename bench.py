@@ -143,6 +143,23 @@ def cpu_baseline(T, order, seconds_budget=15.0):
                        % (n, B, T))
 
 
+def pmc_traffic(order, B, T):
+    """HBM bytes per lattice launch from the PMC passes committed under profiles/
+    (r01_pmc_lattice_fetch_write.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+    tools/bench_lattice.py at B=512, T'=334; FETCH_SIZE reads half of a 4 B/lane coalesced
+    stream on gfx950 - calibrated on log_softmax_fwd - so traffic = 2*FETCH + WRITE).
+    bench.py cannot collect counters itself; the figure applies to the measured shape only."""
+    if B != 512 or T != 1000:
+        return None
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_lattice_fetch_write.json')
+    try:
+        pmc = json.load(open(path))
+        k = 'lattice_fwbw_sl_kernel<3, 8, 1>' if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>'
+        return (2 * pmc['FETCH_SIZE'][k]['mean_KB'] + pmc['WRITE_SIZE'][k]['mean_KB']) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -260,7 +277,7 @@ def main():
                        'final_loss': float(loss)},
             'roofline': {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': pmc_traffic(order, B, T),
                          'algorithmic_bytes_per_launch': alg,
                          'avg_launch_ms': lat_ms},
         }
