@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0 (see the contract in the task statement), with
                  oracle for the lattice), bounded sample, N = 1 only.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -171,6 +172,8 @@ def main():
     ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS),
                     help='BASELINE config; default ctc (mono-char, the headline metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-hooks', action='store_true',
+                    help='leave out GradientClipping / PolyakDecay (recipe hooks)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -184,7 +187,8 @@ def main():
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
 
     from att_speech import _native, fst_utils
-    from att_speech.dp import FlatGradBucket, broadcast_parameters
+    from att_speech.dp import FlatGradBucket, broadcast_parameters, train_step
+    from att_speech.modules.hooks import GradientClipping, PolyakDecay
     from att_speech.models import SpeechModel
 
     if a.workload:
@@ -212,15 +216,33 @@ def main():
     lat_events = []
     _native.EVENT_HOOK = None
 
+    # the hooks of the recipe that touch gradients / parameters every step
+    # (egs/wsj/yamls/ctc.yaml:90-103): global-norm clipping incl. skip-step (it
+    # sees the all-reduced gradient) and the Polyak average of the state_dict
+    hooks = []
+    if not a.no_hooks:
+        hooks = [GradientClipping(clip_norm=10000.0, skip_step_norm=100000.0),
+                 PolyakDecay(decay_rates=[0.9998])]
+        for h in hooks:
+            h.pre_run(model, opt)
+
+    class _Recorder(object):                 # times the lattice call of the recorded steps
+        def __init__(self):
+            self.on = False
+
+        def __call__(self, *args, **kw):
+            _native.EVENT_HOOK = lat_events if self.on else None
+            try:
+                return model(*args, **kw)
+            finally:
+                _native.EVENT_HOOK = None
+    fwd = _Recorder()
+
     def step(record=False):
-        bucket.zero_()
-        if record:
-            _native.EVENT_HOOK = lat_events
-        out = model(feats_d, lens, None, texts, llens)
-        _native.EVENT_HOOK = None
-        out['loss'].backward()
-        bucket.all_reduce_sum()
-        opt.step()
+        fwd.on = record
+        with contextlib.redirect_stdout(sys.stderr):     # hooks print like the reference; stdout is the JSON line
+            out, _ = train_step(model, opt, ((feats_d, lens, None, texts, llens), {}),
+                                hooks=hooks, bucket=bucket, forward=fwd)
         return out['loss']
 
     def fence():

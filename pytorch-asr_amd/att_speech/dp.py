@@ -70,3 +70,43 @@ def broadcast_parameters(module, src=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src, group=group)
+
+
+def train_step(model, optimizer, batch_args, hooks=(), bucket=None, current_iteration=0,
+               group=None, forward=None):
+    """One training step in the reference's order (trainer.py:229-272):
+    pre_train_forward hooks -> forward -> pre_backward hooks -> zero grads ->
+    backward -> [gradient all-reduce over `bucket`] -> post_backward hooks (they
+    see the GLOBAL gradient, e.g. GradientClipping) -> optimizer.step() unless a
+    hook asked to skip -> post_optimizer_step hooks.  `batch_args` are the
+    arguments of `model.forward` (or of `forward` if given).  Returns
+    (loss_dict, skipped)."""
+    for h in hooks:
+        h.pre_train_forward(model=model, optimizer=optimizer,
+                            current_iteration=current_iteration)
+    fwd = forward if forward is not None else model      # e.g. a wrapper that times the call
+    loss_dict = fwd(*batch_args[0], **batch_args[1]) if isinstance(batch_args, tuple) \
+        else fwd(**batch_args)
+    loss = loss_dict['loss']
+    skip = False
+    for h in hooks:
+        skip = bool(h.pre_backward(model=model, optimizer=optimizer,
+                                   current_iteration=current_iteration, loss=loss)) or skip
+    if bucket is not None:
+        bucket.zero_()
+    else:
+        optimizer.zero_grad()
+    loss.backward()
+    if bucket is not None:
+        bucket.all_reduce_sum(group)
+    for h in hooks:
+        if hasattr(h, 'bucket'):
+            h.bucket = bucket
+        skip = bool(h.post_backward(model=model, optimizer=optimizer,
+                                    current_iteration=current_iteration, loss=loss)) or skip
+    if not skip:
+        optimizer.step()
+    for h in hooks:
+        h.post_optimizer_step(model=model, optimizer=optimizer,
+                              current_iteration=current_iteration, loss=loss)
+    return loss_dict, skip

@@ -52,8 +52,25 @@ def _worker(rank, world, port, q):
         bucket.zero_()
         _loss(model, x[idx], lens[idx]).backward()
         bucket.all_reduce_sum()
+    grads = [p.grad.detach().numpy().copy() for p in model.parameters()]
+    # global-norm clipping after the all-reduce: same decision on every rank
+    from att_speech.dp import train_step
+    from att_speech.modules.hooks import GradientClipping
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, net):
+            super(Wrap, self).__init__()
+            self.net = net
+
+        def forward(self, x, lens):
+            return {'loss': _loss(self.net, x, lens)}
+
+    hook = GradientClipping(clip_norm=0.5)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    train_step(Wrap(model), opt, ((x[idx], lens[idx]), {}), hooks=[hook], bucket=bucket)
+    clip_info = (float(bucket.flat.norm()), hook.gstats[1])
     # plain numpy through the queue: shared-memory tensors need the sender alive until received
-    q.put((rank, idx, [p.grad.detach().numpy().copy() for p in model.parameters()]))
+    q.put((rank, idx, grads, clip_info))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,7 +94,10 @@ def test_dp_gradients_are_the_sum_over_shards():
     lens = torch.tensor([10, 9, 7, 7, 4, 2])
     _loss(model, x, lens).backward()
     want = [p.grad for p in model.parameters()]
-    for rank, idx, grads in res:
+    total = float(torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters())))
+    for rank, idx, grads, (clipped_norm, unclipped) in res:
+        assert abs(unclipped - total) <= 1e-4 * total          # the hook saw the GLOBAL norm
+        assert abs(clipped_norm - 0.5) <= 1e-4
         assert lens[idx].tolist() == sorted(lens[idx].tolist(), reverse=True)
         for a, b in zip(grads, want):
             torch.testing.assert_close(torch.from_numpy(a), b, rtol=1e-5, atol=1e-6)
