@@ -232,6 +232,45 @@ int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
                             void *workspace, int64_t workspace_bytes,
                             void *stream);
 
+/*
+ * BatchNorm2d + Hardtanh(lo, hi) fused over the [B, C, H, W] fp32 output of a
+ * convolution: the `Normalization('batch_norm')` + `nn.Hardtanh(0, 20)` pair of
+ * the DeepSpeech2 conv front-end (deep_speech_2.py:60-73).  training != 0: batch
+ * statistics (biased variance for the normalisation; running_mean / running_var
+ * updated with `momentum` and the unbiased variance like nn.BatchNorm2d, pass
+ * null to leave them alone); training == 0: running statistics.  The clamped
+ * activation is written as fp32 or bf16 (out_bf16), in NCHW or time-major
+ * [H, B, C, W] order (out_time_major: the permute(2,0,1,3) of
+ * deep_speech_2.py:142-146).  channels_last != 0: x (and a non-time-major out /
+ * dy, and dx) are stored [B, H, W, C] — the layout MIOpen's implicit-GEMM
+ * convolutions produce and consume (C must divide 256).  save_mean / save_invstd
+ * [C] feed the backward.
+ * workspace: asr_bn_act_workspace_bytes(C).
+ */
+int64_t asr_bn_act_workspace_bytes(int C);
+int asr_bn_act_fwd_f32(const float *x, int B, int C, int H, int W,
+                       const float *gamma, const float *beta,
+                       float *running_mean, float *running_var,
+                       int channels_last,
+                       int training, float momentum, float eps, float lo, float hi,
+                       void *out, int out_bf16, int out_time_major,
+                       float *save_mean, float *save_invstd,
+                       void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * Backward of the above from the SAVED convolution output x: the Hardtanh mask
+ * (lo < bn(x) < hi, torch's hardtanh_backward) is recomputed, dy is read in the
+ * dtype / layout the forward wrote.  dx [B,C,H,W] fp32, dgamma / dbeta [C].
+ */
+int asr_bn_act_bwd_f32(const float *x, int B, int C, int H, int W,
+                       const float *gamma, const float *beta,
+                       const float *save_mean, const float *save_invstd,
+                       int channels_last,
+                       int training, float lo, float hi,
+                       const void *dy, int dy_bf16, int dy_time_major,
+                       float *dx, float *dgamma, float *dbeta,
+                       void *workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

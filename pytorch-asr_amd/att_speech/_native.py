@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -49,6 +49,11 @@ _SIGNATURES = {
     'asr_lstm_workspace_bytes': (_i64, [_i, _i]),
     'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'asr_bn_act_workspace_bytes': (_i64, [_i]),
+    'asr_bn_act_fwd_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
+                                _vp, _i, _i, _vp, _vp, _vp, _i64, _vp]),
+    'asr_bn_act_bwd_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
+                                _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
 
 
@@ -353,3 +358,73 @@ def build_ctc_graph(labels, label_lens, num_symbols, context_order,
         float(nc_weight), _p(g.src_in), _p(g.il_in), _p(g.w_in), _p(g.term),
         _p(g.dst_out), _p(g.il_out), _p(g.w_out), _stream()), 'asr_ctc_graph_build')
     return g
+
+
+def _nchw_or_nhwc(t, name, dtype):
+    """4-D GPU tensor as stored: (tensor, channels_last flag) without a layout copy when it
+    is dense in either format."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise NativeLibraryError(
+            "%s must be a GPU tensor: the MI355X path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if t.is_contiguous():
+        return t, False
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return t, True
+    return t.contiguous(), False
+
+
+def bn_act_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, lo, hi,
+               out_bf16=False, time_major=False):
+    """asr_bn_act_fwd_f32 on x [B,C,H,W] f32 (NCHW or channels_last storage) ->
+    (out, save_mean [C], save_invstd [C]); out is [B,C,H,W] in x's memory format or,
+    time_major, a dense [H,B,C,W]; running stats are updated in place when training."""
+    x, cl = _nchw_or_nhwc(x, 'x', torch.float32)
+    gamma = _dev(gamma, torch.float32, 'gamma')
+    beta = _dev(beta, torch.float32, 'beta')
+    B, C, H, W = x.shape
+    if cl and (C > 256 or 256 % C):
+        x, cl = x.contiguous(), False
+    L = lib()
+    odt = torch.bfloat16 if out_bf16 else torch.float32
+    if time_major:
+        out = torch.empty((H, B, C, W), dtype=odt, device=x.device)
+    else:
+        out = torch.empty((B, C, H, W), dtype=odt, device=x.device,
+                          memory_format=torch.channels_last if cl else torch.contiguous_format)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    nbytes = L.asr_bn_act_workspace_bytes(C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(L.asr_bn_act_fwd_f32(_p(x), B, C, H, W, _p(gamma), _p(beta), _p(running_mean),
+                               _p(running_var), int(cl), int(bool(training)), float(momentum),
+                               float(eps), float(lo), float(hi), _p(out), int(out_bf16),
+                               int(time_major), _p(mean), _p(invstd), _p(ws), nbytes, _stream()),
+          'asr_bn_act_fwd_f32')
+    return out, mean, invstd
+
+
+def bn_act_bwd(x, gamma, beta, mean, invstd, training, lo, hi, dy, time_major=False):
+    """asr_bn_act_bwd_f32 -> (dx [B,C,H,W] f32 in x's memory format, dgamma [C], dbeta [C]);
+    dy f32 or bf16 in the layout the forward wrote."""
+    x, cl = _nchw_or_nhwc(x, 'x', torch.float32)
+    if dy.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("dy must be float32 or bfloat16")
+    if time_major or not cl:
+        dy = _dev(dy, dy.dtype, 'dy')
+    else:
+        dy = dy.contiguous(memory_format=torch.channels_last)
+    B, C, H, W = x.shape
+    L = lib()
+    dx = torch.empty_like(x)                      # preserves the memory format
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    nbytes = L.asr_bn_act_workspace_bytes(C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(L.asr_bn_act_bwd_f32(_p(x), B, C, H, W, _p(gamma), _p(beta), _p(mean), _p(invstd),
+                               int(cl), int(bool(training)), float(lo), float(hi), _p(dy),
+                               int(dy.dtype == torch.bfloat16), int(time_major), _p(dx),
+                               _p(dgamma), _p(dbeta), _p(ws), nbytes, _stream()),
+          'asr_bn_act_bwd_f32')
+    return dx, dgamma, dbeta

@@ -21,6 +21,7 @@ class DeepSpeech2(BaseEncoder):
         super(DeepSpeech2, self).__init__(**kwargs)
         import os
         self.conv_bf16 = os.environ.get('ASR_CONV_BF16', '1') != '0'
+        self.fused_bn = os.environ.get('ASR_FUSED_BN', '1') != '0'
         if isinstance(rnn_type, str):
             rnn_type = {'LSTM': nn.LSTM, 'GRU': nn.GRU}[rnn_type.split('.')[-1]]
         self.makeConv(sample_batch, conv_strides, conv_kernel_sizes,
@@ -82,30 +83,53 @@ class DeepSpeech2(BaseEncoder):
         self.rnns = SequentialWithOptionalAttributes(OrderedDict(rnns))
 
     def _conv_forward(self, features):
-        """conv stack; on the GPU the 32->32 channel convolution (97 % of the
-        stack's flops) takes bf16 operands with fp32 accumulation, like the
-        LSTM GEMMs (BASELINE config 2: bf16); BatchNorm statistics, Hardtanh and
-        the one-channel first convolution stay fp32."""
-        if not (features.is_cuda and self.conv_bf16 and len(self.conv) == 6
-                and isinstance(self.conv[3], nn.Conv2d)):
-            return self.conv(features)
-        x = self.conv[2](self.conv[1](self.conv[0](features)))
-        c2 = self.conv[3]
-        x = nn.functional.conv2d(
-            x.to(torch.bfloat16), c2.weight.to(torch.bfloat16),
-            None if c2.bias is None else c2.bias.to(torch.bfloat16),
-            c2.stride, c2.padding, c2.dilation, c2.groups)
-        return self.conv[5](self.conv[4](x.float()))
+        """conv stack on [B, ch, T, F] -> [T', B, C*F'] (the permute/view of
+        reference :142-146 included).
+
+        On the GPU (a) the 32->32 channel convolution (97 % of the stack's flops)
+        takes bf16 operands with fp32 accumulation, like the LSTM GEMMs (BASELINE
+        config 2: bf16); the one-channel first convolution stays fp32;
+        (b) BatchNorm2d + Hardtanh run as the fused kernels of csrc/bnact.hip: two
+        passes over the convolution output forward and two backward, the clamped
+        activation written straight as the next consumer's operand (bf16 NCHW for
+        the second convolution, fp32 time-major for the LSTM stack)."""
+        conv = self.conv
+        fused = (features.is_cuda and self.fused_bn and len(conv) == 6
+                 and isinstance(conv[0], nn.Conv2d) and isinstance(conv[3], nn.Conv2d)
+                 and all(isinstance(conv[i], Normalization)
+                         and isinstance(conv[i].batch_norm, nn.BatchNorm2d)
+                         and conv[i].batch_norm.affine for i in (1, 4))
+                 and all(isinstance(conv[i], nn.Hardtanh) for i in (2, 5)))
+        bf16 = features.is_cuda and self.conv_bf16 and len(conv) == 6 \
+            and isinstance(conv[3], nn.Conv2d)
+        c2 = conv[3] if len(conv) == 6 else None
+
+        def second_conv(x):
+            if not bf16:
+                return c2(x.float() if x.dtype != torch.float32 else x)
+            return nn.functional.conv2d(
+                x.to(torch.bfloat16), c2.weight.to(torch.bfloat16),
+                None if c2.bias is None else c2.bias.to(torch.bfloat16),
+                c2.stride, c2.padding, c2.dilation, c2.groups).float()
+
+        if fused:
+            from att_speech.modules.encoders.native_bn import bn_hardtanh
+            x = bn_hardtanh(conv[0](features), conv[1].batch_norm, conv[2], out_bf16=bf16)
+            x = bn_hardtanh(second_conv(x), conv[4].batch_norm, conv[5], time_major=True)
+            return x.view(x.size(0), x.size(1), -1)                  # [T', B, C*F']
+        if bf16:
+            x = conv[5](conv[4](second_conv(conv[2](conv[1](conv[0](features))))))
+        else:
+            x = conv(features)
+        # bs x c x t x f -> t x bs x (c x f)
+        x = x.permute(2, 0, 1, 3).contiguous()
+        return x.view(x.size(0), x.size(1), -1)
 
     def forward(self, features, features_lengths, spkids, ivectors=None,
                 characteristic_vectors=None, **kwargs):
         # bs x t x f x c -> bs x c x t x f
         features = features.permute(0, 3, 1, 2)
         features = self._conv_forward(features)
-        batch_size, _, num_timestp, _ = features.size()
-        # bs x c x t x f -> t x bs x (c x f)
-        features = features.permute(2, 0, 1, 3).contiguous()
-        features = features.view(num_timestp, batch_size, -1)
         features_lengths = torch.as_tensor(features_lengths)
         features_lengths = ((features_lengths + self.conv_cumative_stride - 1)
                             // self.conv_cumative_stride).int()          # (:149-151)

@@ -1,0 +1,45 @@
+"""nn.BatchNorm2d + nn.Hardtanh on the MI355X as one autograd function over the
+fused kernels of csrc/bnact.hip (include/asr_amd.h: asr_bn_act_{fwd,bwd}_f32).
+The modules keep their parameters and buffers (state_dict keys unchanged:
+conv.{1,4}.batch_norm.{weight,bias,running_mean,running_var,num_batches_tracked});
+running statistics follow nn.BatchNorm2d in training mode."""
+import torch
+
+from att_speech import _native
+
+
+class BNHardtanhFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps,
+                lo, hi, out_bf16, time_major):
+        out, mean, invstd = _native.bn_act_fwd(
+            x, gamma.detach(), beta.detach(), running_mean, running_var, training, momentum,
+            eps, lo, hi, out_bf16=out_bf16, time_major=time_major)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.cfg = (training, lo, hi, time_major)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        training, lo, hi, time_major = ctx.cfg
+        dx, dgamma, dbeta = _native.bn_act_bwd(x, gamma.detach(), beta.detach(), mean, invstd,
+                                               training, lo, hi, dy, time_major=time_major)
+        return (dx, dgamma, dbeta) + (None,) * 9
+
+
+def bn_hardtanh(x, bn, act, out_bf16=False, time_major=False):
+    """x [B,C,H,W] f32 GPU tensor -> Hardtanh(BatchNorm2d(x)) as f32 / bf16,
+    [B,C,H,W] or time-major [H,B,C,W]."""
+    use_batch_stats = bn.training or bn.running_mean is None
+    momentum = 0.0
+    rm = rv = None
+    if use_batch_stats and bn.training and bn.track_running_stats and bn.running_mean is not None:
+        bn.num_batches_tracked.add_(1)
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        rm, rv = bn.running_mean, bn.running_var
+    elif not use_batch_stats:
+        rm, rv = bn.running_mean, bn.running_var
+    return BNHardtanhFunction.apply(x.float(), bn.weight, bn.bias, rm, rv, use_batch_stats,
+                                    momentum, bn.eps, float(act.min_val), float(act.max_val),
+                                    out_bf16, time_major)

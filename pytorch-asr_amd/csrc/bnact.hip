@@ -1,0 +1,384 @@
+// BatchNorm2d + Hardtanh of the DeepSpeech2 conv front-end, fused (reference
+// att_speech/modules/encoders/deep_speech_2.py:60-73: Conv2d -> Normalization
+// ('batch_norm', nn.BatchNorm2d) -> Hardtanh(0, 20, inplace)).
+//
+// HBM-bound streaming over the [B, C, H*W] fp32 convolution output (1.1 GB for
+// the first layer at B=512).  torch runs this as: BN statistics, BN normalise,
+// clamp, (cast to bf16 for the next convolution) forward and clamp-backward,
+// BN dx, BN dscale/dbias backward — about twelve passes over the big tensor.
+// Here: one statistics pass + one apply pass forward (the apply writes the
+// clamped activation directly in the dtype / layout its consumer wants: bf16
+// NCHW for the next convolution, or fp32 time-major [T, B, C, F] for the LSTM
+// stack), one reduction pass + one apply pass backward (the clamp mask is
+// recomputed from the saved convolution output).
+//
+// One workgroup per (b, c) plane; per-channel sums are accumulated in double
+// with one atomic pair per workgroup.
+#include "common.h"
+#include "../../include/asr_amd.h"
+
+namespace {
+
+using namespace asr;
+
+struct BnParams {
+    const float *x;          // [B, C, HW] convolution output
+    int B, C, HW, Wd;        // Wd = W (frequency bins); HW = H*W
+    const float *gamma, *beta;
+    const float *mean, *invstd;   // [C]
+    float lo, hi;
+};
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float *x, int C, int HW, double *sums) {
+    __shared__ float red[64];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float *p = x + ((size_t)b * C + c) * HW;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float v = p[i];
+        s += v;
+        q += v * v;
+    }
+    s = block_sum(s, red);
+    q = block_sum(q, red + 32);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * c], (double)s);
+        atomicAdd(&sums[2 * c + 1], (double)q);
+    }
+}
+
+// mean / biased variance -> invstd; running statistics as nn.BatchNorm2d in
+// training mode (unbiased variance, momentum)
+__global__ void bn_finalize_kernel(const double *sums, int C, double n, float eps, float momentum,
+                                   float *mean, float *invstd, float *running_mean,
+                                   float *running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[2 * c] / n;
+    double var = sums[2 * c + 1] / n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_stats_kernel(const float *running_mean, const float *running_var, int C,
+                                     float eps, float *mean, float *invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = running_mean[c];
+    invstd[c] = 1.f / sqrtf(running_var[c] + eps);
+}
+
+// LAYOUT 0: out[b][c][hw];  LAYOUT 1: out[h][b][c][w] (time-major, deep_speech_2.py:142-146)
+template <typename OutT, int LAYOUT>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnParams p, OutT *out) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float *x = p.x + ((size_t)b * p.C + c) * p.HW;
+    const float sc = p.gamma[c] * p.invstd[c], sh = p.beta[c] - p.mean[c] * sc;
+    for (int i = threadIdx.x; i < p.HW; i += 256) {
+        const float y = fminf(fmaxf(fmaf(x[i], sc, sh), p.lo), p.hi);
+        size_t o;
+        if (LAYOUT == 0) {
+            o = ((size_t)b * p.C + c) * p.HW + i;
+        } else {
+            const int h = i / p.Wd, w = i - h * p.Wd;
+            o = (((size_t)h * p.B + b) * p.C + c) * p.Wd + w;
+        }
+        out[o] = (OutT)y;
+    }
+}
+
+template <typename DyT, int LAYOUT>
+__device__ __forceinline__ float load_dy(const BnParams &p, const DyT *dy, int b, int c, int i) {
+    size_t o;
+    if (LAYOUT == 0) {
+        o = ((size_t)b * p.C + c) * p.HW + i;
+    } else {
+        const int h = i / p.Wd, w = i - h * p.Wd;
+        o = (((size_t)h * p.B + b) * p.C + c) * p.Wd + w;
+    }
+    return (float)dy[o];
+}
+
+// sums[c] = { sum dyh, sum dyh * xhat } with dyh = dy where lo < bn(x) < hi (hardtanh_backward)
+template <typename DyT, int LAYOUT>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnParams p, const DyT *dy, double *sums) {
+    __shared__ float red[64];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float *x = p.x + ((size_t)b * p.C + c) * p.HW;
+    const float m = p.mean[c], is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < p.HW; i += 256) {
+        const float xh = (x[i] - m) * is;
+        const float y = fmaf(xh, g, be);
+        const float d = (y > p.lo && y < p.hi) ? load_dy<DyT, LAYOUT>(p, dy, b, c, i) : 0.f;
+        s += d;
+        q += d * xh;
+    }
+    s = block_sum(s, red);
+    q = block_sum(q, red + 32);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * c], (double)s);
+        atomicAdd(&sums[2 * c + 1], (double)q);
+    }
+}
+
+// dx = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)) in training mode,
+// gamma*invstd*dyh with running statistics
+template <typename DyT, int LAYOUT>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnParams p, const DyT *dy, const double *sums,
+                                                               double n, int training, float *dx) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float *x = p.x + ((size_t)b * p.C + c) * p.HW;
+    float *o = dx + ((size_t)b * p.C + c) * p.HW;
+    const float m = p.mean[c], is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
+    const float k1 = training ? (float)(sums[2 * c] / n) : 0.f;
+    const float k2 = training ? (float)(sums[2 * c + 1] / n) : 0.f;
+    const float gi = g * is;
+    for (int i = threadIdx.x; i < p.HW; i += 256) {
+        const float xh = (x[i] - m) * is;
+        const float y = fmaf(xh, g, be);
+        const float d = (y > p.lo && y < p.hi) ? load_dy<DyT, LAYOUT>(p, dy, b, c, i) : 0.f;
+        o[i] = gi * (d - k1 - xh * k2);
+    }
+}
+
+
+// ---- channels-last input: x[p][c], p = (b*H + h)*W + w.  MIOpen's implicit-GEMM
+// convolutions produce and consume this layout, so the big activations never get
+// transposed.  Thread (pl, c): lane = channel (C divides 256), 256/C pixels per
+// pass, every access a fully coalesced C*4-byte row.
+struct BnParamsN {
+    const float *x;
+    int64_t P;               // pixels
+    int B, C, H, W;
+    const float *gamma, *beta, *mean, *invstd;
+    float lo, hi;
+};
+
+__device__ __forceinline__ void nhwc_block_atomics(float s, float q, int C, double *sums) {
+    __shared__ float rs[256], rq[256];
+    rs[threadIdx.x] = s;
+    rq[threadIdx.x] = q;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float a = 0.f, b = 0.f;
+        for (int i = threadIdx.x; i < 256; i += C) { a += rs[i]; b += rq[i]; }
+        atomicAdd(&sums[2 * threadIdx.x], (double)a);
+        atomicAdd(&sums[2 * threadIdx.x + 1], (double)b);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_nhwc_kernel(const float *x, int64_t P, int C, double *sums) {
+    const int PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
+    const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
+    float s = 0.f, q = 0.f;
+    for (int64_t p = p0 + pl; p < p1; p += PL) {
+        const float v = x[p * C + c];
+        s += v;
+        q += v * v;
+    }
+    nhwc_block_atomics(s, q, C, sums);
+}
+
+// time-major output / dy index of pixel p, channel c: [H][B][C][W]
+__device__ __forceinline__ size_t tm_index(const BnParamsN &p, int64_t pix, int c) {
+    const int w = (int)(pix % p.W);
+    const int64_t r = pix / p.W;
+    const int h = (int)(r % p.H), b = (int)(r / p.H);
+    return (((size_t)h * p.B + b) * p.C + c) * p.W + w;
+}
+
+template <typename OutT, int TM>
+__global__ __launch_bounds__(256) void bn_act_fwd_nhwc_kernel(BnParamsN p, OutT *out) {
+    const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
+    const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
+    const float sc = p.gamma[c] * p.invstd[c], sh = p.beta[c] - p.mean[c] * sc;
+    for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
+        const float y = fminf(fmaxf(fmaf(p.x[pix * C + c], sc, sh), p.lo), p.hi);
+        out[TM ? tm_index(p, pix, c) : (size_t)(pix * C + c)] = (OutT)y;
+    }
+}
+
+template <typename DyT, int TM>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_nhwc_kernel(BnParamsN p, const DyT *dy, double *sums) {
+    const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
+    const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
+    const float m = p.mean[c], is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
+    float s = 0.f, q = 0.f;
+    for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
+        const float xh = (p.x[pix * C + c] - m) * is;
+        const float y = fmaf(xh, g, be);
+        const float d = (y > p.lo && y < p.hi)
+                            ? (float)dy[TM ? tm_index(p, pix, c) : (size_t)(pix * C + c)] : 0.f;
+        s += d;
+        q += d * xh;
+    }
+    nhwc_block_atomics(s, q, C, sums);
+}
+
+template <typename DyT, int TM>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_nhwc_kernel(BnParamsN p, const DyT *dy, const double *sums,
+                                                                    double n, int training, float *dx) {
+    const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
+    const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
+    const float m = p.mean[c], is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
+    const float k1 = training ? (float)(sums[2 * c] / n) : 0.f;
+    const float k2 = training ? (float)(sums[2 * c + 1] / n) : 0.f;
+    const float gi = g * is;
+    for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
+        const float xh = (p.x[pix * C + c] - m) * is;
+        const float y = fmaf(xh, g, be);
+        const float d = (y > p.lo && y < p.hi)
+                            ? (float)dy[TM ? tm_index(p, pix, c) : (size_t)(pix * C + c)] : 0.f;
+        dx[pix * C + c] = gi * (d - k1 - xh * k2);
+    }
+}
+
+__global__ void bn_param_grads_kernel(const double *sums, int C, float *dgamma, float *dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)sums[2 * c];
+    dgamma[c] = (float)sums[2 * c + 1];
+}
+
+__global__ void zero_doubles_kernel(double *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
+inline bool bad_shape(int B, int C, int H, int W) {
+    return B <= 0 || C <= 0 || H <= 0 || W <= 0 || C > 65535 || B > 65535 ||
+           (int64_t)H * W > 0x7fffffff;
+}
+
+}  // namespace
+
+extern "C" int64_t asr_bn_act_workspace_bytes(int C) { return C < 0 ? -1 : (int64_t)C * 2 * 8 + 64; }
+
+extern "C" int asr_bn_act_fwd_f32(const float *x, int B, int C, int H, int W,
+                                  const float *gamma, const float *beta,
+                                  float *running_mean, float *running_var,
+                                  int channels_last,
+                                  int training, float momentum, float eps, float lo, float hi,
+                                  void *out, int out_bf16, int out_time_major,
+                                  float *save_mean, float *save_invstd,
+                                  void *workspace, int64_t workspace_bytes, void *stream) {
+    if (bad_shape(B, C, H, W) || !x || !gamma || !beta || !out || !save_mean || !save_invstd)
+        return ASR_EINVAL;
+    if (!training && (!running_mean || !running_var)) return ASR_EINVAL;
+    if (!workspace || workspace_bytes < asr_bn_act_workspace_bytes(C)) return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    double *sums = (double *)workspace;
+    const int HW = H * W;
+    const dim3 grid(C, B);
+    if (channels_last && (C > 256 || 256 % C != 0)) return ASR_EUNSUPPORTED;
+    const int64_t P = (int64_t)B * HW;
+    const int nwg = (int)(P / 64 < 4096 ? (P / 64 > 0 ? P / 64 : 1) : 4096);
+    if (training) {
+        hipLaunchKernelGGL(zero_doubles_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, 2 * C);
+        if (channels_last)
+            hipLaunchKernelGGL(bn_stats_nhwc_kernel, dim3(nwg), dim3(256), 0, s, x, P, C, sums);
+        else
+            hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, x, C, HW, sums);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C,
+                           (double)B * HW, eps, momentum, save_mean, save_invstd, running_mean,
+                           running_var);
+    } else {
+        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, s, running_mean,
+                           running_var, C, eps, save_mean, save_invstd);
+    }
+    BnParams p;
+    p.x = x; p.B = B; p.C = C; p.HW = HW; p.Wd = W; p.gamma = gamma; p.beta = beta;
+    p.mean = save_mean; p.invstd = save_invstd; p.lo = lo; p.hi = hi;
+    if (channels_last) {
+        BnParamsN q;
+        q.x = x; q.P = P; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma; q.beta = beta;
+        q.mean = save_mean; q.invstd = save_invstd; q.lo = lo; q.hi = hi;
+        if (out_bf16) {
+            if (out_time_major) hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<__bf16, 1>), dim3(nwg), dim3(256), 0, s, q, (__bf16 *)out);
+            else hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<__bf16, 0>), dim3(nwg), dim3(256), 0, s, q, (__bf16 *)out);
+        } else {
+            if (out_time_major) hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<float, 1>), dim3(nwg), dim3(256), 0, s, q, (float *)out);
+            else hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<float, 0>), dim3(nwg), dim3(256), 0, s, q, (float *)out);
+        }
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
+    if (out_bf16) {
+        if (out_time_major) hipLaunchKernelGGL((bn_act_fwd_kernel<__bf16, 1>), grid, dim3(256), 0, s, p, (__bf16 *)out);
+        else hipLaunchKernelGGL((bn_act_fwd_kernel<__bf16, 0>), grid, dim3(256), 0, s, p, (__bf16 *)out);
+    } else {
+        if (out_time_major) hipLaunchKernelGGL((bn_act_fwd_kernel<float, 1>), grid, dim3(256), 0, s, p, (float *)out);
+        else hipLaunchKernelGGL((bn_act_fwd_kernel<float, 0>), grid, dim3(256), 0, s, p, (float *)out);
+    }
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_bn_act_bwd_f32(const float *x, int B, int C, int H, int W,
+                                  const float *gamma, const float *beta,
+                                  const float *save_mean, const float *save_invstd,
+                                  int channels_last,
+                                  int training, float lo, float hi,
+                                  const void *dy, int dy_bf16, int dy_time_major,
+                                  float *dx, float *dgamma, float *dbeta,
+                                  void *workspace, int64_t workspace_bytes, void *stream) {
+    if (bad_shape(B, C, H, W) || !x || !gamma || !beta || !save_mean || !save_invstd || !dy ||
+        !dx || !dgamma || !dbeta)
+        return ASR_EINVAL;
+    if (!workspace || workspace_bytes < asr_bn_act_workspace_bytes(C)) return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    double *sums = (double *)workspace;
+    const int HW = H * W;
+    const dim3 grid(C, B);
+    BnParams p;
+    p.x = x; p.B = B; p.C = C; p.HW = HW; p.Wd = W; p.gamma = gamma; p.beta = beta;
+    p.mean = save_mean; p.invstd = save_invstd; p.lo = lo; p.hi = hi;
+    const double n = (double)B * HW;
+    hipLaunchKernelGGL(zero_doubles_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, 2 * C);
+    if (channels_last) {
+        if (C > 256 || 256 % C != 0) return ASR_EUNSUPPORTED;
+        BnParamsN q;
+        q.x = x; q.P = (int64_t)B * HW; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma;
+        q.beta = beta; q.mean = save_mean; q.invstd = save_invstd; q.lo = lo; q.hi = hi;
+        const int nwg = (int)(q.P / 64 < 4096 ? (q.P / 64 > 0 ? q.P / 64 : 1) : 4096);
+#define ASR_BN_BWDN(DT, TMV)                                                                      \
+        do {                                                                                      \
+            hipLaunchKernelGGL((bn_act_bwd_reduce_nhwc_kernel<DT, TMV>), dim3(nwg), dim3(256), 0, \
+                               s, q, (const DT *)dy, sums);                                       \
+            hipLaunchKernelGGL((bn_act_bwd_apply_nhwc_kernel<DT, TMV>), dim3(nwg), dim3(256), 0,  \
+                               s, q, (const DT *)dy, sums, n, training, dx);                      \
+        } while (0)
+        if (dy_bf16) {
+            if (dy_time_major) ASR_BN_BWDN(__bf16, 1); else ASR_BN_BWDN(__bf16, 0);
+        } else {
+            if (dy_time_major) ASR_BN_BWDN(float, 1); else ASR_BN_BWDN(float, 0);
+        }
+#undef ASR_BN_BWDN
+        hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, dgamma, dbeta);
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
+#define ASR_BN_BWD(DT, LAY)                                                                       \
+    do {                                                                                          \
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT, LAY>), grid, dim3(256), 0, s, p,         \
+                           (const DT *)dy, sums);                                                 \
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT, LAY>), grid, dim3(256), 0, s, p,          \
+                           (const DT *)dy, sums, n, training, dx);                                \
+    } while (0)
+    if (dy_bf16) {
+        if (dy_time_major) ASR_BN_BWD(__bf16, 1); else ASR_BN_BWD(__bf16, 0);
+    } else {
+        if (dy_time_major) ASR_BN_BWD(float, 1); else ASR_BN_BWD(float, 0);
+    }
+#undef ASR_BN_BWD
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, dgamma, dbeta);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
