@@ -210,7 +210,8 @@ int asr_lattice_grouped_forward_f32(
  *                      direction [1][2:T+2] — contiguous GEMM operands for dW_hh
  *   gates  [T,2,B,4,H] post-activation gates, csave [T,2,B,H] cell states:
  *                      saved by the forward pass for the backward pass
- *   dy     [T,B,2,H]   gradient w.r.t. y
+ *   dy     [T,B,2,H]   gradient w.r.t. y; dy_shared != 0: [T,B,H], one gradient for
+ *                      both directions (BatchRNN sums them, encoder_utils.py:112-117)
  *   dgates_bf16 [T,B,2,4H] bf16: gradient w.r.t. the gate pre-activations
  *                      (= w.r.t. gx); the caller forms dx, dW_ih, dW_hh from it
  *                      with dense GEMMs (bf16 operands, fp32 accumulation)
@@ -225,7 +226,7 @@ int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
                             void *workspace, int64_t workspace_bytes,
                             void *stream);
 
-int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
+int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
                             const int32_t *lens, int T, int B, int H,
                             const float *gates, const float *csave,
                             void *dgates_bf16,

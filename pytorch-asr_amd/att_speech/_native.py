@@ -48,7 +48,7 @@ _SIGNATURES = {
                                         [_f, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_workspace_bytes': (_i64, [_i, _i]),
     'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_bn_act_workspace_bytes': (_i64, [_i]),
     'asr_bn_act_fwd_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _i64, _vp]),
@@ -260,17 +260,20 @@ def lstm_bidir_fwd(gx, whh_bf16, lens):
 
 
 def lstm_bidir_bwd(dy, whhT_bf16, lens, gates, csave):
-    """asr_lstm_bidir_bwd_bf16 -> dgates [T,B,2,4H] bf16."""
+    """asr_lstm_bidir_bwd_bf16 -> dgates [T,B,2,4H] bf16.  dy [T,B,2,H], or [T,B,H] when
+    the two directions share one gradient (their outputs are summed)."""
     dy = _dev(dy, torch.float32, 'dy')
     whhT_bf16 = _dev(whhT_bf16, torch.bfloat16, 'whhT')
     lens = _dev(lens, torch.int32, 'lens')
-    T, B, _, H = dy.shape
+    shared = dy.dim() == 3
+    T, B = dy.shape[0], dy.shape[1]
+    H = dy.shape[-1]
     L = lib()
     dgates = torch.empty((T, B, 2, 4 * H), dtype=torch.bfloat16, device=dy.device)
     nbytes = L.asr_lstm_workspace_bytes(B, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
-    check(L.asr_lstm_bidir_bwd_bf16(_p(dy), _p(whhT_bf16), _p(lens), T, B, H, _p(gates),
-                                    _p(csave), _p(dgates), _p(ws), nbytes, _stream()),
+    check(L.asr_lstm_bidir_bwd_bf16(_p(dy), int(shared), _p(whhT_bf16), _p(lens), T, B, H,
+                                    _p(gates), _p(csave), _p(dgates), _p(ws), nbytes, _stream()),
           'asr_lstm_bidir_bwd_bf16')
     return dgates
 

@@ -97,9 +97,14 @@ class BatchRNN(nn.Module):
             flat = x[mask]
             x = x.clone()
             x[mask] = self.batch_norm(flat)
+        summed = False
         if self._use_native(x):
             from att_speech.modules.encoders.native_lstm import bilstm
-            y = bilstm(x, lens_t, self.rnn).view(T, B, -1)      # [T,B,2H], zeros on padding
+            # the direction sum of :112-117 happens inside the function when nothing
+            # sits between the LSTM and the merge
+            summed = self.projection is None and not self.subsample
+            y = bilstm(x, lens_t, self.rnn, sum_dirs=summed)
+            y = y if summed else y.view(T, B, -1)               # [T,B,2H], zeros on padding
         else:
             # host / non-LSTM evaluation with stock torch ops (CPU reference in
             # the tests and bench.py's cpu_baseline; GRU layers)
@@ -111,7 +116,7 @@ class BatchRNN(nn.Module):
             lens_t = lens_t // 2
         if self.projection is not None:
             y = self.projection(y)
-        elif self.bidirectional:
+        elif self.bidirectional and not summed:
             y = y.view(y.size(0), y.size(1), 2, -1).sum(2)      # (T,B,2H) -> (T,B,H)
         if self.residual:
             y = torch.nn.functional.relu(y + res)

@@ -21,10 +21,12 @@ def _mm_f32(a, b):
 
 
 class BiLSTMFunction(torch.autograd.Function):
-    """y[T,B,2,H] = BiLSTM(x[T,B,F]; W_ih[2][4H,F], W_hh[2][4H,H]), masked by lens."""
+    """y[T,B,2,H] = BiLSTM(x[T,B,F]; W_ih[2][4H,F], W_hh[2][4H,H]), masked by lens;
+    sum_dirs: return y.sum(2) [T,B,H] (BatchRNN's merge, encoder_utils.py:112-117) so
+    the backward kernel reads the one shared gradient instead of an expanded copy."""
 
     @staticmethod
-    def forward(ctx, x, lens_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r):
+    def forward(ctx, x, lens_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r, sum_dirs=False):
         T, B, F = x.shape
         H = w_hh_f.shape[1]
         xb = x.reshape(T * B, F).to(torch.bfloat16)
@@ -33,7 +35,7 @@ class BiLSTMFunction(torch.autograd.Function):
         whh = torch.stack([w_hh_f, w_hh_r], 0).to(torch.bfloat16).contiguous()
         y, ybf, gates, csave = _native.lstm_bidir_fwd(gx, whh, lens_dev)
         ctx.save_for_backward(xb, lens_dev, w_ih, whh, ybf, gates, csave)
-        return y
+        return y.sum(2) if sum_dirs else y
 
     @staticmethod
     def backward(ctx, dy):
@@ -52,13 +54,14 @@ class BiLSTMFunction(torch.autograd.Function):
         hp_r = ybf[1, 2:T + 2].reshape(T * B, H)
         dw_hh_f = _mm_f32(dg2[:, :4 * H].t(), hp_f)
         dw_hh_r = _mm_f32(dg2[:, 4 * H:].t(), hp_r)
-        return dx, None, dw_ih[:4 * H], dw_hh_f, dw_ih[4 * H:], dw_hh_r
+        return dx, None, dw_ih[:4 * H], dw_hh_f, dw_ih[4 * H:], dw_hh_r, None
 
 
-def bilstm(x, lens, rnn):
+def bilstm(x, lens, rnn, sum_dirs=False):
     """x [T,B,F] GPU tensor, lens [B] (any int tensor), rnn: nn.LSTM(bidirectional,
-    bias=False, 1 layer).  Returns per-direction outputs [T,B,2,H]."""
+    bias=False, 1 layer).  Returns per-direction outputs [T,B,2,H], or their sum
+    [T,B,H] with sum_dirs."""
     lens_dev = torch.as_tensor(lens).to(x.device, torch.int32)
     return BiLSTMFunction.apply(
         x.contiguous(), lens_dev, rnn.weight_ih_l0, rnn.weight_hh_l0,
-        rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse)
+        rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, sum_dirs)

@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
 }
 
 struct LstmBwdParams {
-    const float *dy;        // [T,B,2,H] gradient w.r.t. the per-direction outputs
+    const float *dy;        // [T,B,2,H] gradient w.r.t. the per-direction outputs, or [T,B,H]
+    int dy_shared;          // != 0: one gradient for both directions (the directions are summed)
     const __bf16 *whhT;     // fragment-major pack of W_hhᵀ: [2 dir][H rows][4H cols]
     const int32_t *lens;
     int T, B, H;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
         const int tpc = tp < 0 ? 0 : (tp >= p.T ? p.T - 1 : tp);
         const float cpv = p.csave[(((size_t)tpc * 2 + dir) * B + bc) * H + j];
         pcp[e] = (tp >= 0 && tp < len) ? cpv : 0.f;
-        pdy[e] = p.dy[(((size_t)t * B + bc) * 2 + dir) * H + j];
+        pdy[e] = p.dy[p.dy_shared ? ((size_t)t * B + bc) * H + j : (((size_t)t * B + bc) * 2 + dir) * H + j];
         pdc[e] = p.dcbuf[((size_t)dir * B + bc) * H + j];
     }
 
@@ -664,7 +665,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
 #pragma unroll
             for (int g = 0; g < 4; ++g) q.g[e][g] = p.gates[gsave + (size_t)g * H];
             q.cp[e] = p.csave[(((size_t)tpc * 2 + dir) * B + bcl[e]) * H + j];
-            q.dy[e] = p.dy[(((size_t)t * B + bcl[e]) * 2 + dir) * H + j];
+            q.dy[e] = p.dy[p.dy_shared ? ((size_t)t * B + bcl[e]) * H + j
+                                       : (((size_t)t * B + bcl[e]) * 2 + dir) * H + j];
         }
     };
     Pre cur;
@@ -920,7 +922,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
-extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
+extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
                                        const int32_t *lens, int T, int B, int H,
                                        const float *gates, const float *csave,
                                        void *dgates_bf16,
@@ -936,7 +938,7 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, const void *whhT_bf16,
     const size_t Bp = (size_t)(B + 63) / 64 * 64;
     const size_t dbytes = (size_t)2 * 2 * Bp * 4 * H * 2, cbytes = (size_t)2 * B * H * 4;
     __bf16 *wpack = (__bf16 *)((char *)workspace + dbytes + cbytes);
-    p.dy = dy; p.whhT = wpack; p.lens = lens;
+    p.dy = dy; p.dy_shared = dy_shared; p.whhT = wpack; p.lens = lens;
     p.T = T; p.B = B; p.H = H;
     p.gates = gates; p.csave = csave;
     p.dgbuf = (__bf16 *)workspace;

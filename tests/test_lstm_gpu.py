@@ -23,7 +23,8 @@ def _ref(x, lens, rnn, dy):
     (60, 40, 352, 320, None),          # first encoder layer shape, 2 batch tiles
     (12, 33, 320, 320, None),
 ])
-def test_bilstm_matches_packed_torch_lstm(T, B, F, H, lens):
+@pytest.mark.parametrize('sum_dirs', [False, True])
+def test_bilstm_matches_packed_torch_lstm(T, B, F, H, lens, sum_dirs):
     from att_speech.modules.encoders.native_lstm import bilstm
     torch.manual_seed(T * 1000 + B)
     if lens is None:
@@ -35,6 +36,9 @@ def test_bilstm_matches_packed_torch_lstm(T, B, F, H, lens):
     dy = torch.randn(T, B, 2 * H)
     mask = (torch.arange(T)[:, None] < lens_t[None, :]).float()[:, :, None]
     dy = dy * mask
+    if sum_dirs:        # BatchRNN's merge: the two directions share one gradient
+        g = dy.view(T, B, 2, H)[:, :, 0].contiguous()
+        dy = torch.stack([g, g], 2).view(T, B, 2 * H)
     y_ref, dx_ref, dw_ref = _ref(x, lens_t, rnn, dy)
 
     dev = torch.device('cuda:0')
@@ -42,8 +46,14 @@ def test_bilstm_matches_packed_torch_lstm(T, B, F, H, lens):
     rnn_g.load_state_dict(rnn.state_dict())
     rnn_g.to(dev)
     xg = x.to(dev).requires_grad_()
-    y = bilstm(xg, lens_t, rnn_g).view(T, B, 2 * H)
-    y.backward(dy.to(dev))
+    if sum_dirs:
+        y = bilstm(xg, lens_t, rnn_g, sum_dirs=True)
+        assert tuple(y.shape) == (T, B, H)
+        y.backward(g.to(dev))
+        y_ref = y_ref.view(T, B, 2, H).sum(2)
+    else:
+        y = bilstm(xg, lens_t, rnn_g).view(T, B, 2 * H)
+        y.backward(dy.to(dev))
 
     def close(a, b, what, rtol):
         a, b = a.detach().cpu(), b.detach().cpu()
