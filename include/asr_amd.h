@@ -245,11 +245,14 @@ int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf1
  * deep_speech_2.py:142-146).  channels_last != 0: x (and a non-time-major out /
  * dy, and dx) are stored [B, H, W, C] — the layout MIOpen's implicit-GEMM
  * convolutions produce and consume (C must divide 256).  save_mean / save_invstd
- * [C] feed the backward.
+ * [C] feed the backward.  conv_bias [C] (or null): the bias of the convolution that
+ * produced x, added on the fly (x is then the bias-free convolution), so the
+ * framework needs neither the broadcast add nor the full-tensor reduction for its
+ * gradient; the backward returns that gradient in dconv_bias (may be null).
  * workspace: asr_bn_act_workspace_bytes(C).
  */
 int64_t asr_bn_act_workspace_bytes(int C);
-int asr_bn_act_fwd_f32(const float *x, int B, int C, int H, int W,
+int asr_bn_act_fwd_f32(const float *x, const float *conv_bias, int B, int C, int H, int W,
                        const float *gamma, const float *beta,
                        float *running_mean, float *running_var,
                        int channels_last,
@@ -263,13 +266,13 @@ int asr_bn_act_fwd_f32(const float *x, int B, int C, int H, int W,
  * (lo < bn(x) < hi, torch's hardtanh_backward) is recomputed, dy is read in the
  * dtype / layout the forward wrote.  dx [B,C,H,W] fp32, dgamma / dbeta [C].
  */
-int asr_bn_act_bwd_f32(const float *x, int B, int C, int H, int W,
+int asr_bn_act_bwd_f32(const float *x, const float *conv_bias, int B, int C, int H, int W,
                        const float *gamma, const float *beta,
                        const float *save_mean, const float *save_invstd,
                        int channels_last,
                        int training, float lo, float hi,
                        const void *dy, int dy_bf16, int dy_time_major,
-                       float *dx, float *dgamma, float *dbeta,
+                       float *dx, float *dgamma, float *dbeta, float *dconv_bias,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus

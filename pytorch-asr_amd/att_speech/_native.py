@@ -50,10 +50,10 @@ _SIGNATURES = {
     'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_bn_act_workspace_bytes': (_i64, [_i]),
-    'asr_bn_act_fwd_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
+    'asr_bn_act_fwd_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _i64, _vp]),
-    'asr_bn_act_bwd_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
-                                _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'asr_bn_act_bwd_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
+                                _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
 
 
@@ -379,7 +379,7 @@ def _nchw_or_nhwc(t, name, dtype):
 
 
 def bn_act_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, lo, hi,
-               out_bf16=False, time_major=False):
+               out_bf16=False, time_major=False, conv_bias=None):
     """asr_bn_act_fwd_f32 on x [B,C,H,W] f32 (NCHW or channels_last storage) ->
     (out, save_mean [C], save_invstd [C]); out is [B,C,H,W] in x's memory format or,
     time_major, a dense [H,B,C,W]; running stats are updated in place when training."""
@@ -400,7 +400,9 @@ def bn_act_fwd(x, gamma, beta, running_mean, running_var, training, momentum, ep
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     nbytes = L.asr_bn_act_workspace_bytes(C)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    check(L.asr_bn_act_fwd_f32(_p(x), B, C, H, W, _p(gamma), _p(beta), _p(running_mean),
+    if conv_bias is not None:
+        conv_bias = _dev(conv_bias, torch.float32, 'conv_bias')
+    check(L.asr_bn_act_fwd_f32(_p(x), _p(conv_bias), B, C, H, W, _p(gamma), _p(beta), _p(running_mean),
                                _p(running_var), int(cl), int(bool(training)), float(momentum),
                                float(eps), float(lo), float(hi), _p(out), int(out_bf16),
                                int(time_major), _p(mean), _p(invstd), _p(ws), nbytes, _stream()),
@@ -408,8 +410,10 @@ def bn_act_fwd(x, gamma, beta, running_mean, running_var, training, momentum, ep
     return out, mean, invstd
 
 
-def bn_act_bwd(x, gamma, beta, mean, invstd, training, lo, hi, dy, time_major=False):
-    """asr_bn_act_bwd_f32 -> (dx [B,C,H,W] f32 in x's memory format, dgamma [C], dbeta [C]);
+def bn_act_bwd(x, gamma, beta, mean, invstd, training, lo, hi, dy, time_major=False,
+               conv_bias=None):
+    """asr_bn_act_bwd_f32 -> (dx [B,C,H,W] f32 in x's memory format, dgamma [C], dbeta [C],
+    dconv_bias [C] | None);
     dy f32 or bf16 in the layout the forward wrote."""
     x, cl = _nchw_or_nhwc(x, 'x', torch.float32)
     if dy.dtype not in (torch.float32, torch.bfloat16):
@@ -423,11 +427,15 @@ def bn_act_bwd(x, gamma, beta, mean, invstd, training, lo, hi, dy, time_major=Fa
     dx = torch.empty_like(x)                      # preserves the memory format
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    dcb = None
+    if conv_bias is not None:
+        conv_bias = _dev(conv_bias, torch.float32, 'conv_bias')
+        dcb = torch.empty(C, dtype=torch.float32, device=x.device)
     nbytes = L.asr_bn_act_workspace_bytes(C)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    check(L.asr_bn_act_bwd_f32(_p(x), B, C, H, W, _p(gamma), _p(beta), _p(mean), _p(invstd),
+    check(L.asr_bn_act_bwd_f32(_p(x), _p(conv_bias), B, C, H, W, _p(gamma), _p(beta), _p(mean), _p(invstd),
                                int(cl), int(bool(training)), float(lo), float(hi), _p(dy),
                                int(dy.dtype == torch.bfloat16), int(time_major), _p(dx),
-                               _p(dgamma), _p(dbeta), _p(ws), nbytes, _stream()),
+                               _p(dgamma), _p(dbeta), _p(dcb), _p(ws), nbytes, _stream()),
           'asr_bn_act_bwd_f32')
-    return dx, dgamma, dbeta
+    return dx, dgamma, dbeta, dcb

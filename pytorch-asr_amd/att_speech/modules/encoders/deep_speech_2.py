@@ -104,18 +104,28 @@ class DeepSpeech2(BaseEncoder):
             and isinstance(conv[3], nn.Conv2d)
         c2 = conv[3] if len(conv) == 6 else None
 
-        def second_conv(x):
+        def second_conv(x, with_bias=True):
+            bias = c2.bias if with_bias else None
             if not bf16:
-                return c2(x.float() if x.dtype != torch.float32 else x)
+                return nn.functional.conv2d(x.float() if x.dtype != torch.float32 else x,
+                                            c2.weight, bias, c2.stride, c2.padding,
+                                            c2.dilation, c2.groups)
             return nn.functional.conv2d(
                 x.to(torch.bfloat16), c2.weight.to(torch.bfloat16),
-                None if c2.bias is None else c2.bias.to(torch.bfloat16),
+                None if bias is None else bias.to(torch.bfloat16),
                 c2.stride, c2.padding, c2.dilation, c2.groups).float()
 
         if fused:
+            # the convolutions run bias-free; their biases are folded into the fused
+            # BatchNorm kernels (no broadcast add, no full-tensor reduction for the
+            # bias gradient)
             from att_speech.modules.encoders.native_bn import bn_hardtanh
-            x = bn_hardtanh(conv[0](features), conv[1].batch_norm, conv[2], out_bf16=bf16)
-            x = bn_hardtanh(second_conv(x), conv[4].batch_norm, conv[5], time_major=True)
+            c1 = conv[0]
+            x = nn.functional.conv2d(features, c1.weight, None, c1.stride, c1.padding,
+                                     c1.dilation, c1.groups)
+            x = bn_hardtanh(x, conv[1].batch_norm, conv[2], out_bf16=bf16, conv_bias=c1.bias)
+            x = bn_hardtanh(second_conv(x, with_bias=False), conv[4].batch_norm, conv[5],
+                            time_major=True, conv_bias=c2.bias)
             return x.view(x.size(0), x.size(1), -1)                  # [T', B, C*F']
         if bf16:
             x = conv[5](conv[4](second_conv(conv[2](conv[1](conv[0](features))))))

@@ -10,27 +10,32 @@ from att_speech import _native
 
 class BNHardtanhFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps,
-                lo, hi, out_bf16, time_major):
+    def forward(ctx, x, gamma, beta, conv_bias, running_mean, running_var, training, momentum,
+                eps, lo, hi, out_bf16, time_major):
         out, mean, invstd = _native.bn_act_fwd(
             x, gamma.detach(), beta.detach(), running_mean, running_var, training, momentum,
-            eps, lo, hi, out_bf16=out_bf16, time_major=time_major)
-        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+            eps, lo, hi, out_bf16=out_bf16, time_major=time_major,
+            conv_bias=None if conv_bias is None else conv_bias.detach())
+        ctx.has_cb = conv_bias is not None
+        ctx.save_for_backward(x, gamma, beta, mean, invstd,
+                              conv_bias if conv_bias is not None else gamma)
         ctx.cfg = (training, lo, hi, time_major)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        x, gamma, beta, mean, invstd, cb = ctx.saved_tensors
         training, lo, hi, time_major = ctx.cfg
-        dx, dgamma, dbeta = _native.bn_act_bwd(x, gamma.detach(), beta.detach(), mean, invstd,
-                                               training, lo, hi, dy, time_major=time_major)
-        return (dx, dgamma, dbeta) + (None,) * 9
+        dx, dgamma, dbeta, dcb = _native.bn_act_bwd(
+            x, gamma.detach(), beta.detach(), mean, invstd, training, lo, hi, dy,
+            time_major=time_major, conv_bias=cb.detach() if ctx.has_cb else None)
+        return (dx, dgamma, dbeta, dcb) + (None,) * 9
 
 
-def bn_hardtanh(x, bn, act, out_bf16=False, time_major=False):
-    """x [B,C,H,W] f32 GPU tensor -> Hardtanh(BatchNorm2d(x)) as f32 / bf16,
-    [B,C,H,W] or time-major [H,B,C,W]."""
+def bn_hardtanh(x, bn, act, out_bf16=False, time_major=False, conv_bias=None):
+    """x [B,C,H,W] f32 GPU tensor -> Hardtanh(BatchNorm2d(x + conv_bias)) as f32 / bf16,
+    [B,C,H,W] or time-major [H,B,C,W]; conv_bias [C] is the bias of the convolution
+    that produced x when it was run without it."""
     use_batch_stats = bn.training or bn.running_mean is None
     momentum = 0.0
     rm = rv = None
@@ -40,6 +45,6 @@ def bn_hardtanh(x, bn, act, out_bf16=False, time_major=False):
         rm, rv = bn.running_mean, bn.running_var
     elif not use_batch_stats:
         rm, rv = bn.running_mean, bn.running_var
-    return BNHardtanhFunction.apply(x.float(), bn.weight, bn.bias, rm, rv, use_batch_stats,
+    return BNHardtanhFunction.apply(x.float(), bn.weight, bn.bias, conv_bias, rm, rv, use_batch_stats,
                                     momentum, bn.eps, float(act.min_val), float(act.max_val),
                                     out_bf16, time_major)

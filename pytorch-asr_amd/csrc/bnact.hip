@@ -26,16 +26,18 @@ struct BnParams {
     int B, C, HW, Wd;        // Wd = W (frequency bins); HW = H*W
     const float *gamma, *beta;
     const float *mean, *invstd;   // [C]
+    const float *shift;      // [C] or null: the convolution's bias, added on the fly
     float lo, hi;
 };
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float *x, int C, int HW, double *sums) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float *x, const float *shift, int C, int HW, double *sums) {
     __shared__ float red[64];
     const int c = blockIdx.x, b = blockIdx.y;
     const float *p = x + ((size_t)b * C + c) * HW;
+    const float sh0 = shift ? shift[c] : 0.f;
     float s = 0.f, q = 0.f;
     for (int i = threadIdx.x; i < HW; i += 256) {
-        const float v = p[i];
+        const float v = p[i] + sh0;
         s += v;
         q += v * v;
     }
@@ -79,7 +81,8 @@ template <typename OutT, int LAYOUT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnParams p, OutT *out) {
     const int c = blockIdx.x, b = blockIdx.y;
     const float *x = p.x + ((size_t)b * p.C + c) * p.HW;
-    const float sc = p.gamma[c] * p.invstd[c], sh = p.beta[c] - p.mean[c] * sc;
+    const float sc = p.gamma[c] * p.invstd[c];
+    const float sh = p.beta[c] - (p.mean[c] - (p.shift ? p.shift[c] : 0.f)) * sc;
     for (int i = threadIdx.x; i < p.HW; i += 256) {
         const float y = fminf(fmaxf(fmaf(x[i], sc, sh), p.lo), p.hi);
         size_t o;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnParams p, cons
     __shared__ float red[64];
     const int c = blockIdx.x, b = blockIdx.y;
     const float *x = p.x + ((size_t)b * p.C + c) * p.HW;
-    const float m = p.mean[c], is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
+    const float m = p.mean[c] - (p.shift ? p.shift[c] : 0.f), is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
     float s = 0.f, q = 0.f;
     for (int i = threadIdx.x; i < p.HW; i += 256) {
         const float xh = (x[i] - m) * is;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnParams p, const
     const int c = blockIdx.x, b = blockIdx.y;
     const float *x = p.x + ((size_t)b * p.C + c) * p.HW;
     float *o = dx + ((size_t)b * p.C + c) * p.HW;
-    const float m = p.mean[c], is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
+    const float m = p.mean[c] - (p.shift ? p.shift[c] : 0.f), is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
     const float k1 = training ? (float)(sums[2 * c] / n) : 0.f;
     const float k2 = training ? (float)(sums[2 * c + 1] / n) : 0.f;
     const float gi = g * is;
@@ -158,6 +161,7 @@ struct BnParamsN {
     int64_t P;               // pixels
     int B, C, H, W;
     const float *gamma, *beta, *mean, *invstd;
+    const float *shift;      // [C] or null: the convolution's bias, added on the fly
     float lo, hi;
 };
 
@@ -174,13 +178,14 @@ __device__ __forceinline__ void nhwc_block_atomics(float s, float q, int C, doub
     }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_nhwc_kernel(const float *x, int64_t P, int C, double *sums) {
+__global__ __launch_bounds__(256) void bn_stats_nhwc_kernel(const float *x, const float *shift, int64_t P, int C, double *sums) {
     const int PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
     const int64_t per = (P + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
+    const float sh0 = shift ? shift[c] : 0.f;
     float s = 0.f, q = 0.f;
     for (int64_t p = p0 + pl; p < p1; p += PL) {
-        const float v = x[p * C + c];
+        const float v = x[p * C + c] + sh0;
         s += v;
         q += v * v;
     }
@@ -200,7 +205,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_nhwc_kernel(BnParamsN p, OutT 
     const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
     const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
-    const float sc = p.gamma[c] * p.invstd[c], sh = p.beta[c] - p.mean[c] * sc;
+    const float sc = p.gamma[c] * p.invstd[c];
+    const float sh = p.beta[c] - (p.mean[c] - (p.shift ? p.shift[c] : 0.f)) * sc;
     for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
         const float y = fminf(fmaxf(fmaf(p.x[pix * C + c], sc, sh), p.lo), p.hi);
         out[TM ? tm_index(p, pix, c) : (size_t)(pix * C + c)] = (OutT)y;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_nhwc_kernel(BnParamsN p
     const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
     const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
-    const float m = p.mean[c], is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
+    const float m = p.mean[c] - (p.shift ? p.shift[c] : 0.f), is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
     float s = 0.f, q = 0.f;
     for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
         const float xh = (p.x[pix * C + c] - m) * is;
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_nhwc_kernel(BnParamsN p,
     const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
     const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
-    const float m = p.mean[c], is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
+    const float m = p.mean[c] - (p.shift ? p.shift[c] : 0.f), is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
     const float k1 = training ? (float)(sums[2 * c] / n) : 0.f;
     const float k2 = training ? (float)(sums[2 * c + 1] / n) : 0.f;
     const float gi = g * is;
@@ -244,11 +250,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_nhwc_kernel(BnParamsN p,
     }
 }
 
-__global__ void bn_param_grads_kernel(const double *sums, int C, float *dgamma, float *dbeta) {
+// dgamma, dbeta, and the gradient of the folded-in convolution bias: sum of dx over
+// all pixels = gamma*invstd*sum(dyh) with running statistics, exactly 0 with batch
+// statistics (sum of xhat is 0 by construction)
+__global__ void bn_param_grads_kernel(const double *sums, int C, const float *gamma,
+                                      const float *invstd, int training, float *dgamma,
+                                      float *dbeta, float *dshift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     dbeta[c] = (float)sums[2 * c];
     dgamma[c] = (float)sums[2 * c + 1];
+    if (dshift) dshift[c] = training ? 0.f : gamma[c] * invstd[c] * (float)sums[2 * c];
 }
 
 __global__ void zero_doubles_kernel(double *p, int n) {
@@ -265,7 +277,7 @@ inline bool bad_shape(int B, int C, int H, int W) {
 
 extern "C" int64_t asr_bn_act_workspace_bytes(int C) { return C < 0 ? -1 : (int64_t)C * 2 * 8 + 64; }
 
-extern "C" int asr_bn_act_fwd_f32(const float *x, int B, int C, int H, int W,
+extern "C" int asr_bn_act_fwd_f32(const float *x, const float *conv_bias, int B, int C, int H, int W,
                                   const float *gamma, const float *beta,
                                   float *running_mean, float *running_var,
                                   int channels_last,
@@ -287,9 +299,9 @@ extern "C" int asr_bn_act_fwd_f32(const float *x, int B, int C, int H, int W,
     if (training) {
         hipLaunchKernelGGL(zero_doubles_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, 2 * C);
         if (channels_last)
-            hipLaunchKernelGGL(bn_stats_nhwc_kernel, dim3(nwg), dim3(256), 0, s, x, P, C, sums);
+            hipLaunchKernelGGL(bn_stats_nhwc_kernel, dim3(nwg), dim3(256), 0, s, x, conv_bias, P, C, sums);
         else
-            hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, x, C, HW, sums);
+            hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, x, conv_bias, C, HW, sums);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C,
                            (double)B * HW, eps, momentum, save_mean, save_invstd, running_mean,
                            running_var);
@@ -299,11 +311,11 @@ extern "C" int asr_bn_act_fwd_f32(const float *x, int B, int C, int H, int W,
     }
     BnParams p;
     p.x = x; p.B = B; p.C = C; p.HW = HW; p.Wd = W; p.gamma = gamma; p.beta = beta;
-    p.mean = save_mean; p.invstd = save_invstd; p.lo = lo; p.hi = hi;
+    p.mean = save_mean; p.invstd = save_invstd; p.shift = conv_bias; p.lo = lo; p.hi = hi;
     if (channels_last) {
         BnParamsN q;
         q.x = x; q.P = P; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma; q.beta = beta;
-        q.mean = save_mean; q.invstd = save_invstd; q.lo = lo; q.hi = hi;
+        q.mean = save_mean; q.invstd = save_invstd; q.shift = conv_bias; q.lo = lo; q.hi = hi;
         if (out_bf16) {
             if (out_time_major) hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<__bf16, 1>), dim3(nwg), dim3(256), 0, s, q, (__bf16 *)out);
             else hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<__bf16, 0>), dim3(nwg), dim3(256), 0, s, q, (__bf16 *)out);
@@ -323,13 +335,13 @@ extern "C" int asr_bn_act_fwd_f32(const float *x, int B, int C, int H, int W,
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
-extern "C" int asr_bn_act_bwd_f32(const float *x, int B, int C, int H, int W,
+extern "C" int asr_bn_act_bwd_f32(const float *x, const float *conv_bias, int B, int C, int H, int W,
                                   const float *gamma, const float *beta,
                                   const float *save_mean, const float *save_invstd,
                                   int channels_last,
                                   int training, float lo, float hi,
                                   const void *dy, int dy_bf16, int dy_time_major,
-                                  float *dx, float *dgamma, float *dbeta,
+                                  float *dx, float *dgamma, float *dbeta, float *dconv_bias,
                                   void *workspace, int64_t workspace_bytes, void *stream) {
     if (bad_shape(B, C, H, W) || !x || !gamma || !beta || !save_mean || !save_invstd || !dy ||
         !dx || !dgamma || !dbeta)
@@ -341,14 +353,14 @@ extern "C" int asr_bn_act_bwd_f32(const float *x, int B, int C, int H, int W,
     const dim3 grid(C, B);
     BnParams p;
     p.x = x; p.B = B; p.C = C; p.HW = HW; p.Wd = W; p.gamma = gamma; p.beta = beta;
-    p.mean = save_mean; p.invstd = save_invstd; p.lo = lo; p.hi = hi;
+    p.mean = save_mean; p.invstd = save_invstd; p.shift = conv_bias; p.lo = lo; p.hi = hi;
     const double n = (double)B * HW;
     hipLaunchKernelGGL(zero_doubles_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, 2 * C);
     if (channels_last) {
         if (C > 256 || 256 % C != 0) return ASR_EUNSUPPORTED;
         BnParamsN q;
         q.x = x; q.P = (int64_t)B * HW; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma;
-        q.beta = beta; q.mean = save_mean; q.invstd = save_invstd; q.lo = lo; q.hi = hi;
+        q.beta = beta; q.mean = save_mean; q.invstd = save_invstd; q.shift = conv_bias; q.lo = lo; q.hi = hi;
         const int nwg = (int)(q.P / 64 < 4096 ? (q.P / 64 > 0 ? q.P / 64 : 1) : 4096);
 #define ASR_BN_BWDN(DT, TMV)                                                                      \
         do {                                                                                      \
@@ -363,7 +375,7 @@ extern "C" int asr_bn_act_bwd_f32(const float *x, int B, int C, int H, int W,
             if (dy_time_major) ASR_BN_BWDN(float, 1); else ASR_BN_BWDN(float, 0);
         }
 #undef ASR_BN_BWDN
-        hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
 #define ASR_BN_BWD(DT, LAY)                                                                       \
@@ -379,6 +391,6 @@ extern "C" int asr_bn_act_bwd_f32(const float *x, int B, int C, int H, int W,
         if (dy_time_major) ASR_BN_BWD(float, 1); else ASR_BN_BWD(float, 0);
     }
 #undef ASR_BN_BWD
-    hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }

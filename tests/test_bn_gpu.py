@@ -78,3 +78,44 @@ def test_bn_hardtanh_bf16_output_is_the_rounded_fp32_one():
     xg = x.clone().requires_grad_()
     bn_hardtanh(xg, bn2, act, out_bf16=True).backward(torch.ones_like(y16))
     assert torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_folded_conv_bias(training, channels_last):
+    """conv_bias: the convolution ran bias-free, the fused kernels add its bias on the
+    fly and return its gradient (sum of dx; exactly 0 with batch statistics)."""
+    from att_speech.modules.encoders.native_bn import bn_hardtanh
+    torch.manual_seed(5)
+    B, C, H, W = 4, 32, 21, 9
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C) * 8 + 0.5)
+        bn.bias.copy_(torch.randn(C) * 4 + 6)
+        bn.running_var.copy_(torch.rand(C) + 0.5)
+    bn.train(training)
+    act = nn.Hardtanh(0, 20)
+    x = torch.randn(B, C, H, W) * 1.5
+    cb = torch.randn(C)
+    dy = torch.randn(B, C, H, W)
+    ref_bn = copy.deepcopy(bn)
+    xr, cbr = x.clone().requires_grad_(), cb.clone().requires_grad_()
+    yr = act(ref_bn(xr + cbr[None, :, None, None]))
+    yr.backward(dy)
+
+    dev = torch.device('cuda:0')
+    bn.to(dev)
+    xg = x.to(dev)
+    if channels_last:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    xg.requires_grad_()
+    cbg = cb.to(dev).requires_grad_()
+    y = bn_hardtanh(xg, bn, act, conv_bias=cbg)
+    y.backward(dy.to(dev))
+    torch.testing.assert_close(y.detach().cpu(), yr.detach(), rtol=1e-5, atol=1e-4)
+    scale = float(xr.grad.abs().max()) + 1e-6
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 2e-4 * scale
+    # the reference's bias gradient is rounding noise around 0 in training mode
+    tol = 2e-4 * (float(cbr.grad.abs().max()) + 1e-6) + (2e-3 if training else 0.0)
+    assert float((cbg.grad.cpu() - cbr.grad).abs().max()) <= tol
+    torch.testing.assert_close(bn.running_mean.cpu(), ref_bn.running_mean, rtol=1e-5, atol=1e-6)
