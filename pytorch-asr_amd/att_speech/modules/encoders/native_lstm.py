@@ -20,6 +20,13 @@ def _mm_f32(a, b):
         return torch.mm(a, b).float()
 
 
+def _bmm_f32(a, b):
+    try:
+        return torch.bmm(a, b, out_dtype=torch.float32)
+    except (TypeError, RuntimeError):
+        return torch.bmm(a, b).float()
+
+
 class BiLSTMFunction(torch.autograd.Function):
     """y[T,B,2,H] = BiLSTM(x[T,B,F]; W_ih[2][4H,F], W_hh[2][4H,H]), masked by lens;
     sum_dirs: return y.sum(2) [T,B,H] (BatchRNN's merge, encoder_utils.py:112-117) so
@@ -48,13 +55,16 @@ class BiLSTMFunction(torch.autograd.Function):
         dg2 = dgb.view(T * B, 2 * 4 * H)                                 # bf16
         dx = _mm_f32(dg2, w_ih).view(T, B, F)
         dw_ih = _mm_f32(dg2.t(), xb)                                     # [2*4H, F]
-        # h_{t-1}: forward direction looks one frame back, reverse one frame
-        # ahead — contiguous slices of the zero-padded bf16 copy
-        hp_f = ybf[0, 0:T].reshape(T * B, H)
-        hp_r = ybf[1, 2:T + 2].reshape(T * B, H)
-        dw_hh_f = _mm_f32(dg2[:, :4 * H].t(), hp_f)
-        dw_hh_r = _mm_f32(dg2[:, 4 * H:].t(), hp_r)
-        return dx, None, dw_ih[:4 * H], dw_hh_f, dw_ih[4 * H:], dw_hh_r, None
+        # h_{t-1}: forward direction looks one frame back (frames 0..T-1 of its
+        # zero-padded plane), reverse one frame ahead (frames 2..T+1 of the next
+        # plane) — the two slices are (T+4)*B*H elements apart, so both weight
+        # gradients are ONE batched GEMM [2][4H x TB] x [2][TB x H]: twice the
+        # workgroups per launch of the two K = T*B reductions (each alone fills
+        # 100 of 256 CUs)
+        hp = ybf.as_strided((2, T * B, H), ((T + 4) * B * H, H, 1))
+        dgT = dgb.view(T * B, 2, 4 * H).permute(1, 2, 0)                 # [2, 4H, TB], no copy
+        dw_hh = _bmm_f32(dgT, hp)                                        # [2, 4H, H]
+        return dx, None, dw_ih[:4 * H], dw_hh[0], dw_ih[4 * H:], dw_hh[1], None
 
 
 def bilstm(x, lens, rnn, sum_dirs=False):
