@@ -178,3 +178,22 @@ def test_ctc_decoder_advanced_matches_torch_ctc():
     frames = logits.argmax(-1).transpose(0, 1)
     np.testing.assert_array_equal(res['decoded_frames'].numpy(), frames.numpy())
     assert res['decoded'] == ref.process_sequences(frames, elens)
+
+
+def test_skinny_projection_backward_matches_linear():
+    """LutLinear's GPU backward (chunked dW / bias reductions) against F.linear's."""
+    from att_speech.modules.decoders.advanced_decoder import _SkinnyLinear
+    torch.manual_seed(1)
+    d = dev()
+    x = torch.randn(96, 64, 40, device=d)
+    w = torch.randn(49, 40, device=d)
+    b = torch.randn(49, device=d)
+    dy = torch.randn(96, 64, 49, device=d)
+    ref = [t.clone().requires_grad_() for t in (x, w, b)]
+    torch.nn.functional.linear(*ref).backward(dy)
+    got = [t.clone().requires_grad_() for t in (x, w, b)]
+    y = _SkinnyLinear.apply(*got)
+    y.backward(dy)
+    assert torch.equal(y, torch.nn.functional.linear(x, w, b))
+    for a, r in zip(got, ref):
+        torch.testing.assert_close(a.grad, r.grad, rtol=1e-4, atol=1e-3)
