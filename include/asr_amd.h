@@ -234,8 +234,8 @@ int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf1
                             void *stream);
 
 /*
- * BatchNorm2d + Hardtanh(lo, hi) fused over the [B, C, H, W] fp32 output of a
- * convolution: the `Normalization('batch_norm')` + `nn.Hardtanh(0, 20)` pair of
+ * BatchNorm2d + Hardtanh(lo, hi) fused over the [B, C, H, W] output of a
+ * convolution (fp32, or bf16 with x_bf16 — channels-last only; dx then is bf16 too): the `Normalization('batch_norm')` + `nn.Hardtanh(0, 20)` pair of
  * the DeepSpeech2 conv front-end (deep_speech_2.py:60-73).  training != 0: batch
  * statistics (biased variance for the normalisation; running_mean / running_var
  * updated with `momentum` and the unbiased variance like nn.BatchNorm2d, pass
@@ -252,7 +252,7 @@ int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf1
  * workspace: asr_bn_act_workspace_bytes(C).
  */
 int64_t asr_bn_act_workspace_bytes(int C);
-int asr_bn_act_fwd_f32(const float *x, const float *conv_bias, int B, int C, int H, int W,
+int asr_bn_act_fwd_f32(const void *x, int x_bf16, const float *conv_bias, int B, int C, int H, int W,
                        const float *gamma, const float *beta,
                        float *running_mean, float *running_var,
                        int channels_last,
@@ -266,13 +266,13 @@ int asr_bn_act_fwd_f32(const float *x, const float *conv_bias, int B, int C, int
  * (lo < bn(x) < hi, torch's hardtanh_backward) is recomputed, dy is read in the
  * dtype / layout the forward wrote.  dx [B,C,H,W] fp32, dgamma / dbeta [C].
  */
-int asr_bn_act_bwd_f32(const float *x, const float *conv_bias, int B, int C, int H, int W,
+int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_bias, int B, int C, int H, int W,
                        const float *gamma, const float *beta,
                        const float *save_mean, const float *save_invstd,
                        int channels_last,
                        int training, float lo, float hi,
                        const void *dy, int dy_bf16, int dy_time_major,
-                       float *dx, float *dgamma, float *dbeta, float *dconv_bias,
+                       void *dx, float *dgamma, float *dbeta, float *dconv_bias,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus

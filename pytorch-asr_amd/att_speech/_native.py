@@ -50,9 +50,9 @@ _SIGNATURES = {
     'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_bn_act_workspace_bytes': (_i64, [_i]),
-    'asr_bn_act_fwd_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
+    'asr_bn_act_fwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _i64, _vp]),
-    'asr_bn_act_bwd_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
+    'asr_bn_act_bwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
 
@@ -380,15 +380,18 @@ def _nchw_or_nhwc(t, name, dtype):
 
 def bn_act_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, lo, hi,
                out_bf16=False, time_major=False, conv_bias=None):
-    """asr_bn_act_fwd_f32 on x [B,C,H,W] f32 (NCHW or channels_last storage) ->
+    """asr_bn_act_fwd_f32 on x [B,C,H,W] f32 (NCHW or channels_last storage) or bf16
+    (channels_last) ->
     (out, save_mean [C], save_invstd [C]); out is [B,C,H,W] in x's memory format or,
     time_major, a dense [H,B,C,W]; running stats are updated in place when training."""
-    x, cl = _nchw_or_nhwc(x, 'x', torch.float32)
+    x, cl = _nchw_or_nhwc(x, 'x', x.dtype if x.dtype == torch.bfloat16 else torch.float32)
     gamma = _dev(gamma, torch.float32, 'gamma')
     beta = _dev(beta, torch.float32, 'beta')
     B, C, H, W = x.shape
     if cl and (C > 256 or 256 % C):
         x, cl = x.contiguous(), False
+    if x.dtype == torch.bfloat16 and not cl:        # bf16 input is a channels-last path
+        x = x.float()
     L = lib()
     odt = torch.bfloat16 if out_bf16 else torch.float32
     if time_major:
@@ -402,7 +405,7 @@ def bn_act_fwd(x, gamma, beta, running_mean, running_var, training, momentum, ep
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     if conv_bias is not None:
         conv_bias = _dev(conv_bias, torch.float32, 'conv_bias')
-    check(L.asr_bn_act_fwd_f32(_p(x), _p(conv_bias), B, C, H, W, _p(gamma), _p(beta), _p(running_mean),
+    check(L.asr_bn_act_fwd_f32(_p(x), int(x.dtype == torch.bfloat16), _p(conv_bias), B, C, H, W, _p(gamma), _p(beta), _p(running_mean),
                                _p(running_var), int(cl), int(bool(training)), float(momentum),
                                float(eps), float(lo), float(hi), _p(out), int(out_bf16),
                                int(time_major), _p(mean), _p(invstd), _p(ws), nbytes, _stream()),
@@ -415,7 +418,9 @@ def bn_act_bwd(x, gamma, beta, mean, invstd, training, lo, hi, dy, time_major=Fa
     """asr_bn_act_bwd_f32 -> (dx [B,C,H,W] f32 in x's memory format, dgamma [C], dbeta [C],
     dconv_bias [C] | None);
     dy f32 or bf16 in the layout the forward wrote."""
-    x, cl = _nchw_or_nhwc(x, 'x', torch.float32)
+    x, cl = _nchw_or_nhwc(x, 'x', x.dtype if x.dtype == torch.bfloat16 else torch.float32)
+    if x.dtype == torch.bfloat16 and not cl:
+        x = x.float()
     if dy.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("dy must be float32 or bfloat16")
     if time_major or not cl:
@@ -433,7 +438,7 @@ def bn_act_bwd(x, gamma, beta, mean, invstd, training, lo, hi, dy, time_major=Fa
         dcb = torch.empty(C, dtype=torch.float32, device=x.device)
     nbytes = L.asr_bn_act_workspace_bytes(C)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    check(L.asr_bn_act_bwd_f32(_p(x), _p(conv_bias), B, C, H, W, _p(gamma), _p(beta), _p(mean), _p(invstd),
+    check(L.asr_bn_act_bwd_f32(_p(x), int(x.dtype == torch.bfloat16), _p(conv_bias), B, C, H, W, _p(gamma), _p(beta), _p(mean), _p(invstd),
                                int(cl), int(bool(training)), float(lo), float(hi), _p(dy),
                                int(dy.dtype == torch.bfloat16), int(time_major), _p(dx),
                                _p(dgamma), _p(dbeta), _p(dcb), _p(ws), nbytes, _stream()),

@@ -86,9 +86,10 @@ class DeepSpeech2(BaseEncoder):
         """conv stack on [B, ch, T, F] -> [T', B, C*F'] (the permute/view of
         reference :142-146 included).
 
-        On the GPU (a) the 32->32 channel convolution (97 % of the stack's flops)
-        takes bf16 operands with fp32 accumulation, like the LSTM GEMMs (BASELINE
-        config 2: bf16); the one-channel first convolution stays fp32;
+        On the GPU (a) the convolutions take bf16 operands with fp32 accumulation,
+        like the LSTM GEMMs (BASELINE config 2: bf16) — with the fused BatchNorm
+        kernels both of them, their bf16 outputs being read directly; without, only
+        the 32->32 channel one (97 % of the stack's flops);
         (b) BatchNorm2d + Hardtanh run as the fused kernels of csrc/bnact.hip: two
         passes over the convolution output forward and two backward, the clamped
         activation written straight as the next consumer's operand (bf16 NCHW for
@@ -104,16 +105,20 @@ class DeepSpeech2(BaseEncoder):
             and isinstance(conv[3], nn.Conv2d)
         c2 = conv[3] if len(conv) == 6 else None
 
-        def second_conv(x, with_bias=True):
-            bias = c2.bias if with_bias else None
+        def run_conv(c, x, with_bias=True, keep_bf16=False):
+            bias = c.bias if with_bias else None
             if not bf16:
                 return nn.functional.conv2d(x.float() if x.dtype != torch.float32 else x,
-                                            c2.weight, bias, c2.stride, c2.padding,
-                                            c2.dilation, c2.groups)
-            return nn.functional.conv2d(
-                x.to(torch.bfloat16), c2.weight.to(torch.bfloat16),
+                                            c.weight, bias, c.stride, c.padding,
+                                            c.dilation, c.groups)
+            y = nn.functional.conv2d(
+                x.to(torch.bfloat16), c.weight.to(torch.bfloat16),
                 None if bias is None else bias.to(torch.bfloat16),
-                c2.stride, c2.padding, c2.dilation, c2.groups).float()
+                c.stride, c.padding, c.dilation, c.groups)
+            return y if keep_bf16 else y.float()
+
+        def second_conv(x, with_bias=True):
+            return run_conv(c2, x, with_bias)
 
         if fused:
             # the convolutions run bias-free; their biases are folded into the fused
@@ -121,11 +126,10 @@ class DeepSpeech2(BaseEncoder):
             # bias gradient)
             from att_speech.modules.encoders.native_bn import bn_hardtanh
             c1 = conv[0]
-            x = nn.functional.conv2d(features, c1.weight, None, c1.stride, c1.padding,
-                                     c1.dilation, c1.groups)
+            x = run_conv(c1, features, with_bias=False, keep_bf16=True)
             x = bn_hardtanh(x, conv[1].batch_norm, conv[2], out_bf16=bf16, conv_bias=c1.bias)
-            x = bn_hardtanh(second_conv(x, with_bias=False), conv[4].batch_norm, conv[5],
-                            time_major=True, conv_bias=c2.bias)
+            x = bn_hardtanh(run_conv(c2, x, with_bias=False, keep_bf16=True),
+                            conv[4].batch_norm, conv[5], time_major=True, conv_bias=c2.bias)
             return x.view(x.size(0), x.size(1), -1)                  # [T', B, C*F']
         if bf16:
             x = conv[5](conv[4](second_conv(conv[2](conv[1](conv[0](features))))))

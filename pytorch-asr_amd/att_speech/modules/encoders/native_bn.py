@@ -45,6 +45,8 @@ def bn_hardtanh(x, bn, act, out_bf16=False, time_major=False, conv_bias=None):
         rm, rv = bn.running_mean, bn.running_var
     elif not use_batch_stats:
         rm, rv = bn.running_mean, bn.running_var
-    return BNHardtanhFunction.apply(x.float(), bn.weight, bn.bias, conv_bias, rm, rv, use_batch_stats,
+    if x.dtype != torch.bfloat16:
+        x = x.float()
+    return BNHardtanhFunction.apply(x, bn.weight, bn.bias, conv_bias, rm, rv, use_batch_stats,
                                     momentum, bn.eps, float(act.min_val), float(act.max_val),
                                     out_bf16, time_major)

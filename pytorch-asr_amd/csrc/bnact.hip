@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnParams p, const
 // transposed.  Thread (pl, c): lane = channel (C divides 256), 256/C pixels per
 // pass, every access a fully coalesced C*4-byte row.
 struct BnParamsN {
-    const float *x;
+    const void *x;           // float or __bf16 (template XT), dx has the same type
     int64_t P;               // pixels
     int B, C, H, W;
     const float *gamma, *beta, *mean, *invstd;
@@ -178,14 +178,15 @@ __device__ __forceinline__ void nhwc_block_atomics(float s, float q, int C, doub
     }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_nhwc_kernel(const float *x, const float *shift, int64_t P, int C, double *sums) {
+template <typename XT>
+__global__ __launch_bounds__(256) void bn_stats_nhwc_kernel(const XT *x, const float *shift, int64_t P, int C, double *sums) {
     const int PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
     const int64_t per = (P + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
     const float sh0 = shift ? shift[c] : 0.f;
     float s = 0.f, q = 0.f;
     for (int64_t p = p0 + pl; p < p1; p += PL) {
-        const float v = x[p * C + c] + sh0;
+        const float v = (float)x[p * C + c] + sh0;
         s += v;
         q += v * v;
     }
@@ -200,28 +201,30 @@ __device__ __forceinline__ size_t tm_index(const BnParamsN &p, int64_t pix, int 
     return (((size_t)h * p.B + b) * p.C + c) * p.W + w;
 }
 
-template <typename OutT, int TM>
+template <typename XT, typename OutT, int TM>
 __global__ __launch_bounds__(256) void bn_act_fwd_nhwc_kernel(BnParamsN p, OutT *out) {
+    const XT *px = (const XT *)p.x;
     const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
     const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
     const float sc = p.gamma[c] * p.invstd[c];
     const float sh = p.beta[c] - (p.mean[c] - (p.shift ? p.shift[c] : 0.f)) * sc;
     for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
-        const float y = fminf(fmaxf(fmaf(p.x[pix * C + c], sc, sh), p.lo), p.hi);
+        const float y = fminf(fmaxf(fmaf((float)px[pix * C + c], sc, sh), p.lo), p.hi);
         out[TM ? tm_index(p, pix, c) : (size_t)(pix * C + c)] = (OutT)y;
     }
 }
 
-template <typename DyT, int TM>
+template <typename XT, typename DyT, int TM>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_nhwc_kernel(BnParamsN p, const DyT *dy, double *sums) {
+    const XT *px = (const XT *)p.x;
     const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
     const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
     const float m = p.mean[c] - (p.shift ? p.shift[c] : 0.f), is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
     float s = 0.f, q = 0.f;
     for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
-        const float xh = (p.x[pix * C + c] - m) * is;
+        const float xh = ((float)px[pix * C + c] - m) * is;
         const float y = fmaf(xh, g, be);
         const float d = (y > p.lo && y < p.hi)
                             ? (float)dy[TM ? tm_index(p, pix, c) : (size_t)(pix * C + c)] : 0.f;
@@ -231,9 +234,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_nhwc_kernel(BnParamsN p
     nhwc_block_atomics(s, q, C, sums);
 }
 
-template <typename DyT, int TM>
+template <typename XT, typename DyT, int TM>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_nhwc_kernel(BnParamsN p, const DyT *dy, const double *sums,
-                                                                    double n, int training, float *dx) {
+                                                                    double n, int training, XT *dx) {
+    const XT *px = (const XT *)p.x;
     const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
     const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
@@ -242,11 +246,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_nhwc_kernel(BnParamsN p,
     const float k2 = training ? (float)(sums[2 * c + 1] / n) : 0.f;
     const float gi = g * is;
     for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
-        const float xh = (p.x[pix * C + c] - m) * is;
+        const float xh = ((float)px[pix * C + c] - m) * is;
         const float y = fmaf(xh, g, be);
         const float d = (y > p.lo && y < p.hi)
                             ? (float)dy[TM ? tm_index(p, pix, c) : (size_t)(pix * C + c)] : 0.f;
-        dx[pix * C + c] = gi * (d - k1 - xh * k2);
+        dx[pix * C + c] = (XT)(gi * (d - k1 - xh * k2));
     }
 }
 
@@ -277,7 +281,7 @@ inline bool bad_shape(int B, int C, int H, int W) {
 
 extern "C" int64_t asr_bn_act_workspace_bytes(int C) { return C < 0 ? -1 : (int64_t)C * 2 * 8 + 64; }
 
-extern "C" int asr_bn_act_fwd_f32(const float *x, const float *conv_bias, int B, int C, int H, int W,
+extern "C" int asr_bn_act_fwd_f32(const void *x, int x_bf16, const float *conv_bias, int B, int C, int H, int W,
                                   const float *gamma, const float *beta,
                                   float *running_mean, float *running_var,
                                   int channels_last,
@@ -294,14 +298,16 @@ extern "C" int asr_bn_act_fwd_f32(const float *x, const float *conv_bias, int B,
     const int HW = H * W;
     const dim3 grid(C, B);
     if (channels_last && (C > 256 || 256 % C != 0)) return ASR_EUNSUPPORTED;
+    if (x_bf16 && !channels_last) return ASR_EUNSUPPORTED;   // bf16 input: channels-last only
     const int64_t P = (int64_t)B * HW;
     const int nwg = (int)(P / 64 < 4096 ? (P / 64 > 0 ? P / 64 : 1) : 4096);
     if (training) {
         hipLaunchKernelGGL(zero_doubles_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, 2 * C);
         if (channels_last)
-            hipLaunchKernelGGL(bn_stats_nhwc_kernel, dim3(nwg), dim3(256), 0, s, x, conv_bias, P, C, sums);
+            if (x_bf16) hipLaunchKernelGGL(bn_stats_nhwc_kernel<__bf16>, dim3(nwg), dim3(256), 0, s, (const __bf16 *)x, conv_bias, P, C, sums);
+            else hipLaunchKernelGGL(bn_stats_nhwc_kernel<float>, dim3(nwg), dim3(256), 0, s, (const float *)x, conv_bias, P, C, sums);
         else
-            hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, x, conv_bias, C, HW, sums);
+            hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, (const float *)x, conv_bias, C, HW, sums);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C,
                            (double)B * HW, eps, momentum, save_mean, save_invstd, running_mean,
                            running_var);
@@ -310,19 +316,22 @@ extern "C" int asr_bn_act_fwd_f32(const float *x, const float *conv_bias, int B,
                            running_var, C, eps, save_mean, save_invstd);
     }
     BnParams p;
-    p.x = x; p.B = B; p.C = C; p.HW = HW; p.Wd = W; p.gamma = gamma; p.beta = beta;
+    p.x = (const float *)x; p.B = B; p.C = C; p.HW = HW; p.Wd = W; p.gamma = gamma; p.beta = beta;
     p.mean = save_mean; p.invstd = save_invstd; p.shift = conv_bias; p.lo = lo; p.hi = hi;
     if (channels_last) {
         BnParamsN q;
         q.x = x; q.P = P; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma; q.beta = beta;
         q.mean = save_mean; q.invstd = save_invstd; q.shift = conv_bias; q.lo = lo; q.hi = hi;
-        if (out_bf16) {
-            if (out_time_major) hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<__bf16, 1>), dim3(nwg), dim3(256), 0, s, q, (__bf16 *)out);
-            else hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<__bf16, 0>), dim3(nwg), dim3(256), 0, s, q, (__bf16 *)out);
+#define ASR_BN_FWDN(XT, OT, TMV) \
+        hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<XT, OT, TMV>), dim3(nwg), dim3(256), 0, s, q, (OT *)out)
+        if (x_bf16) {
+            if (out_bf16) { if (out_time_major) ASR_BN_FWDN(__bf16, __bf16, 1); else ASR_BN_FWDN(__bf16, __bf16, 0); }
+            else { if (out_time_major) ASR_BN_FWDN(__bf16, float, 1); else ASR_BN_FWDN(__bf16, float, 0); }
         } else {
-            if (out_time_major) hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<float, 1>), dim3(nwg), dim3(256), 0, s, q, (float *)out);
-            else hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<float, 0>), dim3(nwg), dim3(256), 0, s, q, (float *)out);
+            if (out_bf16) { if (out_time_major) ASR_BN_FWDN(float, __bf16, 1); else ASR_BN_FWDN(float, __bf16, 0); }
+            else { if (out_time_major) ASR_BN_FWDN(float, float, 1); else ASR_BN_FWDN(float, float, 0); }
         }
+#undef ASR_BN_FWDN
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
     if (out_bf16) {
@@ -335,13 +344,13 @@ extern "C" int asr_bn_act_fwd_f32(const float *x, const float *conv_bias, int B,
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
-extern "C" int asr_bn_act_bwd_f32(const float *x, const float *conv_bias, int B, int C, int H, int W,
+extern "C" int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_bias, int B, int C, int H, int W,
                                   const float *gamma, const float *beta,
                                   const float *save_mean, const float *save_invstd,
                                   int channels_last,
                                   int training, float lo, float hi,
                                   const void *dy, int dy_bf16, int dy_time_major,
-                                  float *dx, float *dgamma, float *dbeta, float *dconv_bias,
+                                  void *dx, float *dgamma, float *dbeta, float *dconv_bias,
                                   void *workspace, int64_t workspace_bytes, void *stream) {
     if (bad_shape(B, C, H, W) || !x || !gamma || !beta || !save_mean || !save_invstd || !dy ||
         !dx || !dgamma || !dbeta)
@@ -352,27 +361,30 @@ extern "C" int asr_bn_act_bwd_f32(const float *x, const float *conv_bias, int B,
     const int HW = H * W;
     const dim3 grid(C, B);
     BnParams p;
-    p.x = x; p.B = B; p.C = C; p.HW = HW; p.Wd = W; p.gamma = gamma; p.beta = beta;
+    p.x = (const float *)x; p.B = B; p.C = C; p.HW = HW; p.Wd = W; p.gamma = gamma; p.beta = beta;
     p.mean = save_mean; p.invstd = save_invstd; p.shift = conv_bias; p.lo = lo; p.hi = hi;
     const double n = (double)B * HW;
     hipLaunchKernelGGL(zero_doubles_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, 2 * C);
+    if (x_bf16 && !channels_last) return ASR_EUNSUPPORTED;
     if (channels_last) {
         if (C > 256 || 256 % C != 0) return ASR_EUNSUPPORTED;
         BnParamsN q;
         q.x = x; q.P = (int64_t)B * HW; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma;
         q.beta = beta; q.mean = save_mean; q.invstd = save_invstd; q.shift = conv_bias; q.lo = lo; q.hi = hi;
         const int nwg = (int)(q.P / 64 < 4096 ? (q.P / 64 > 0 ? q.P / 64 : 1) : 4096);
-#define ASR_BN_BWDN(DT, TMV)                                                                      \
+#define ASR_BN_BWDN(XT, DT, TMV)                                                                  \
         do {                                                                                      \
-            hipLaunchKernelGGL((bn_act_bwd_reduce_nhwc_kernel<DT, TMV>), dim3(nwg), dim3(256), 0, \
-                               s, q, (const DT *)dy, sums);                                       \
-            hipLaunchKernelGGL((bn_act_bwd_apply_nhwc_kernel<DT, TMV>), dim3(nwg), dim3(256), 0,  \
-                               s, q, (const DT *)dy, sums, n, training, dx);                      \
+            hipLaunchKernelGGL((bn_act_bwd_reduce_nhwc_kernel<XT, DT, TMV>), dim3(nwg), dim3(256), \
+                               0, s, q, (const DT *)dy, sums);                                    \
+            hipLaunchKernelGGL((bn_act_bwd_apply_nhwc_kernel<XT, DT, TMV>), dim3(nwg), dim3(256),  \
+                               0, s, q, (const DT *)dy, sums, n, training, (XT *)dx);             \
         } while (0)
-        if (dy_bf16) {
-            if (dy_time_major) ASR_BN_BWDN(__bf16, 1); else ASR_BN_BWDN(__bf16, 0);
+        if (x_bf16) {
+            if (dy_bf16) { if (dy_time_major) ASR_BN_BWDN(__bf16, __bf16, 1); else ASR_BN_BWDN(__bf16, __bf16, 0); }
+            else { if (dy_time_major) ASR_BN_BWDN(__bf16, float, 1); else ASR_BN_BWDN(__bf16, float, 0); }
         } else {
-            if (dy_time_major) ASR_BN_BWDN(float, 1); else ASR_BN_BWDN(float, 0);
+            if (dy_bf16) { if (dy_time_major) ASR_BN_BWDN(float, __bf16, 1); else ASR_BN_BWDN(float, __bf16, 0); }
+            else { if (dy_time_major) ASR_BN_BWDN(float, float, 1); else ASR_BN_BWDN(float, float, 0); }
         }
 #undef ASR_BN_BWDN
         hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
@@ -383,7 +395,7 @@ extern "C" int asr_bn_act_bwd_f32(const float *x, const float *conv_bias, int B,
         hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT, LAY>), grid, dim3(256), 0, s, p,         \
                            (const DT *)dy, sums);                                                 \
         hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT, LAY>), grid, dim3(256), 0, s, p,          \
-                           (const DT *)dy, sums, n, training, dx);                                \
+                           (const DT *)dy, sums, n, training, (float *)dx);                       \
     } while (0)
     if (dy_bf16) {
         if (dy_time_major) ASR_BN_BWD(__bf16, 1); else ASR_BN_BWD(__bf16, 0);

@@ -119,3 +119,33 @@ def test_folded_conv_bias(training, channels_last):
     tol = 2e-4 * (float(cbr.grad.abs().max()) + 1e-6) + (2e-3 if training else 0.0)
     assert float((cbg.grad.cpu() - cbr.grad).abs().max()) <= tol
     torch.testing.assert_close(bn.running_mean.cpu(), ref_bn.running_mean, rtol=1e-5, atol=1e-6)
+
+
+def test_bf16_channels_last_input():
+    """The convolutions hand over bf16 channels-last outputs: statistics, activation and
+    gradients must be those of the fp32 computation on the same (bf16-rounded) values."""
+    from att_speech.modules.encoders.native_bn import bn_hardtanh
+    torch.manual_seed(2)
+    dev = torch.device('cuda:0')
+    B, C, H, W = 3, 32, 40, 11
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C) * 8 + 0.5)
+        bn.bias.copy_(torch.randn(C) * 4 + 6)
+    act = nn.Hardtanh(0, 20)
+    xb = (torch.randn(B, C, H, W) * 1.5).to(torch.bfloat16)
+    dy = torch.randn(H, B, C, W)
+    ref_bn = copy.deepcopy(bn)
+    xr = xb.float().requires_grad_()
+    yr = act(ref_bn(xr))
+    yr.backward(dy.permute(1, 2, 0, 3))
+    bn.to(dev)
+    xg = xb.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = bn_hardtanh(xg, bn, act, time_major=True)
+    y.backward(dy.to(dev))
+    assert xg.grad.dtype == torch.bfloat16
+    torch.testing.assert_close(y.permute(1, 2, 0, 3).detach().cpu(), yr.detach(), rtol=1e-5, atol=1e-4)
+    scale = float(xr.grad.abs().max())
+    assert float((xg.grad.float().cpu() - xr.grad).abs().max()) <= 1e-2 * scale      # bf16 dx
+    torch.testing.assert_close(bn.weight.grad.cpu(), ref_bn.weight.grad, rtol=2e-4, atol=1e-3)
+    torch.testing.assert_close(bn.running_var.cpu(), ref_bn.running_var, rtol=1e-5, atol=1e-6)
