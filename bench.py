@@ -33,6 +33,7 @@ import numpy as np                      # noqa: E402
 import torch                            # noqa: E402
 import torch.distributed as dist        # noqa: E402
 
+_STDOUT = sys.stdout
 HBM_PEAK_GBPS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 S = 49                                  # egs/wsj/vocabulary.txt
 
@@ -308,10 +309,13 @@ def main():
             res['cpu_baseline'] = cpu_baseline(T, order)
         else:
             res['cpu_baseline'] = None
-        print(json.dumps(res))
+        print(json.dumps(res), file=_STDOUT, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 if __name__ == '__main__':
-    main()
+    # stdout carries exactly ONE line (the JSON); library / hook chatter goes to stderr
+    _STDOUT = sys.stdout
+    with contextlib.redirect_stdout(sys.stderr):
+        main()
