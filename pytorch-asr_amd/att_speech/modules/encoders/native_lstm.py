@@ -1,5 +1,5 @@
 """Bidirectional bias-free LSTM layer on the MI355X: dense projections as bf16
-GEMMs with fp32 accumulation, the recurrence in the hand-written per-step MFMA
+GEMMs with fp32 accumulation, the recurrence in the hand-written persistent MFMA
 kernels of csrc/lstm.hip (include/asr_amd.h: asr_lstm_bidir_{fwd,bwd}_bf16).
 
 Replaces the vendor LSTM behind `BatchRNN.rnn` (reference

@@ -6,13 +6,19 @@
 // dense GEMM done by the caller; this file owns the sequential part:
 //   gates_t = gx_t + h_{t-1}·W_hhᵀ ;  i,f,o = σ(.), g = tanh(.)
 //   c_t = f·c_{t-1} + i·g ;  h_t = o·tanh(c_t)
-// One launch per time step covers BOTH directions (forward frame s, reverse
-// frame T-1-s) so the grid has 2·(B/32)·(H/32) workgroups.  A workgroup owns a
-// [32 batch x 32 hidden] tile: wave g computes the pre-activation of gate g
-// with v_mfma_f32_32x32x16_bf16 (K = H), operands are read from L2 straight in
-// MFMA fragment order (16 B per lane, k-contiguous; W_hh is 0.8 MB per
-// direction and stays L2-resident across the steps), then the four gate tiles
-// meet in LDS for the pointwise cell update in fp32.
+// Two implementations of the same arithmetic (bit-identical outputs, see
+// tests/test_lstm_gpu.py):
+//   * PERSISTENT (default): one launch walks all T steps; a 512-thread workgroup
+//     keeps its W_hh fragments and the cell state in registers for the whole
+//     sequence and teams of H/64 workgroups hand h_t / dgates_t over through L2
+//     once per step (sc1 write-through + agent-scope counters) — further down;
+//   * PER-STEP (ASR_LSTM_PERSIST=0, and the fallback for shapes the persistent
+//     kernels do not take): one launch per time step covering BOTH directions
+//     (forward frame s, reverse frame T-1-s), grid 2·(B/32)·(H/32); a workgroup
+//     owns a [32 batch x 32 hidden] tile, wave g computes the pre-activation of
+//     gate g with v_mfma_f32_32x32x16_bf16 (K = H), operands read from L2 straight
+//     in MFMA fragment order (W_hh is 0.8 MB per direction and stays L2-resident
+//     across the steps), the four gate tiles meet in LDS for the fp32 cell update.
 //
 // MFMA operand layout: both GEMM operands live in memory in FRAGMENT-MAJOR
 // order — for a [32 rows x K] tile, k-step ks is the 1 KiB block
