@@ -244,7 +244,7 @@ int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf1
  * [H, B, C, W] order (out_time_major: the permute(2,0,1,3) of
  * deep_speech_2.py:142-146).  channels_last != 0: x (and a non-time-major out /
  * dy, and dx) are stored [B, H, W, C] — the layout MIOpen's implicit-GEMM
- * convolutions produce and consume (C must divide 256).  save_mean / save_invstd
+ * convolutions produce and consume (C % 4 == 0 and C/4 must divide 256).  save_mean / save_invstd
  * [C] feed the backward.  conv_bias [C] (or null): the bias of the convolution that
  * produced x, added on the fly (x is then the bias-free convolution), so the
  * framework needs neither the broadcast add nor the full-tensor reduction for its

@@ -388,7 +388,7 @@ def bn_act_fwd(x, gamma, beta, running_mean, running_var, training, momentum, ep
     gamma = _dev(gamma, torch.float32, 'gamma')
     beta = _dev(beta, torch.float32, 'beta')
     B, C, H, W = x.shape
-    if cl and (C > 256 or 256 % C):
+    if cl and (C % 4 or C > 1024 or 256 % (C // 4)):
         x, cl = x.contiguous(), False
     if x.dtype == torch.bfloat16 and not cl:        # bf16 input is a channels-last path
         x = x.float()
@@ -419,6 +419,8 @@ def bn_act_bwd(x, gamma, beta, mean, invstd, training, lo, hi, dy, time_major=Fa
     dconv_bias [C] | None);
     dy f32 or bf16 in the layout the forward wrote."""
     x, cl = _nchw_or_nhwc(x, 'x', x.dtype if x.dtype == torch.bfloat16 else torch.float32)
+    if cl and (x.shape[1] % 4 or x.shape[1] > 1024 or 256 % (x.shape[1] // 4)):
+        x, cl = x.contiguous(), False
     if x.dtype == torch.bfloat16 and not cl:
         x = x.float()
     if dy.dtype not in (torch.float32, torch.bfloat16):

@@ -154,8 +154,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnParams p, const
 
 // ---- channels-last input: x[p][c], p = (b*H + h)*W + w.  MIOpen's implicit-GEMM
 // convolutions produce and consume this layout, so the big activations never get
-// transposed.  Thread (pl, c): lane = channel (C divides 256), 256/C pixels per
-// pass, every access a fully coalesced C*4-byte row.
+// transposed.  A thread owns 4 consecutive channels of a pixel (one 8- or 16-byte
+// access; 2-byte accesses per lane reached only 1.7-2.8 TB/s), C/4 threads cover a
+// pixel, 1024/C pixels per pass; C % 4 == 0 and C/4 divides 256.
 struct BnParamsN {
     const void *x;           // float or __bf16 (template XT), dx has the same type
     int64_t P;               // pixels
@@ -165,30 +166,64 @@ struct BnParamsN {
     float lo, hi;
 };
 
-__device__ __forceinline__ void nhwc_block_atomics(float s, float q, int C, double *sums) {
-    __shared__ float rs[256], rq[256];
-    rs[threadIdx.x] = s;
-    rq[threadIdx.x] = q;
+struct F4 { float v[4]; };
+
+__device__ __forceinline__ F4 load4(const float *p) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    return F4{{t.x, t.y, t.z, t.w}};
+}
+__device__ __forceinline__ F4 load4(const __bf16 *p) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const bf16x4 t = *reinterpret_cast<const bf16x4 *>(p);
+    return F4{{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}};
+}
+__device__ __forceinline__ void store4(float *p, const F4 &a) {
+    *reinterpret_cast<float4 *>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+__device__ __forceinline__ void store4(__bf16 *p, const F4 &a) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 t;
+    t[0] = (__bf16)a.v[0]; t[1] = (__bf16)a.v[1]; t[2] = (__bf16)a.v[2]; t[3] = (__bf16)a.v[3];
+    *reinterpret_cast<bf16x4 *>(p) = t;
+}
+
+// per-channel totals of a workgroup -> two double atomics per channel
+__device__ __forceinline__ void nhwc_block_atomics(const float (&s)[4], const float (&q)[4], int C,
+                                                   double *sums) {
+    __shared__ float rs[256][4], rq[256][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rs[threadIdx.x][i] = s[i]; rq[threadIdx.x][i] = q[i]; }
     __syncthreads();
+    const int CG = C / 4;
     if ((int)threadIdx.x < C) {
+        const int cg = threadIdx.x >> 2, i = threadIdx.x & 3;
         float a = 0.f, b = 0.f;
-        for (int i = threadIdx.x; i < 256; i += C) { a += rs[i]; b += rq[i]; }
+        for (int t = cg; t < 256; t += CG) { a += rs[t][i]; b += rq[t][i]; }
         atomicAdd(&sums[2 * threadIdx.x], (double)a);
         atomicAdd(&sums[2 * threadIdx.x + 1], (double)b);
     }
 }
 
+#define NHWC_THREAD_SETUP(P_)                                                          \
+    const int CG = C / 4, PL = 256 / CG, c0 = 4 * ((int)threadIdx.x % CG),             \
+              pl = (int)threadIdx.x / CG;                                              \
+    const int64_t per = ((P_) + gridDim.x - 1) / gridDim.x;                            \
+    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < (P_) ? p0 + per : (P_)
+
 template <typename XT>
 __global__ __launch_bounds__(256) void bn_stats_nhwc_kernel(const XT *x, const float *shift, int64_t P, int C, double *sums) {
-    const int PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
-    const int64_t per = (P + gridDim.x - 1) / gridDim.x;
-    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
-    const float sh0 = shift ? shift[c] : 0.f;
-    float s = 0.f, q = 0.f;
+    NHWC_THREAD_SETUP(P);
+    float sh0[4], s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sh0[i] = shift ? shift[c0 + i] : 0.f;
     for (int64_t p = p0 + pl; p < p1; p += PL) {
-        const float v = (float)x[p * C + c] + sh0;
-        s += v;
-        q += v * v;
+        const F4 v = load4(x + p * C + c0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float u = v.v[i] + sh0[i];
+            s[i] += u;
+            q[i] += u * u;
+        }
     }
     nhwc_block_atomics(s, q, C, sums);
 }
@@ -204,32 +239,63 @@ __device__ __forceinline__ size_t tm_index(const BnParamsN &p, int64_t pix, int 
 template <typename XT, typename OutT, int TM>
 __global__ __launch_bounds__(256) void bn_act_fwd_nhwc_kernel(BnParamsN p, OutT *out) {
     const XT *px = (const XT *)p.x;
-    const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
-    const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
-    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
-    const float sc = p.gamma[c] * p.invstd[c];
-    const float sh = p.beta[c] - (p.mean[c] - (p.shift ? p.shift[c] : 0.f)) * sc;
-    for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
-        const float y = fminf(fmaxf(fmaf((float)px[pix * C + c], sc, sh), p.lo), p.hi);
-        out[TM ? tm_index(p, pix, c) : (size_t)(pix * C + c)] = (OutT)y;
+    const int C = p.C;
+    NHWC_THREAD_SETUP(p.P);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = p.gamma[c0 + i] * p.invstd[c0 + i];
+        sh[i] = p.beta[c0 + i] - (p.mean[c0 + i] - (p.shift ? p.shift[c0 + i] : 0.f)) * sc[i];
     }
+    for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
+        const F4 v = load4(px + pix * C + c0);
+        F4 y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y.v[i] = fminf(fmaxf(fmaf(v.v[i], sc[i], sh[i]), p.lo), p.hi);
+        if (TM) {
+            const size_t o = tm_index(p, pix, c0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[o + (size_t)i * p.W] = (OutT)y.v[i];
+        } else {
+            store4(out + pix * C + c0, y);
+        }
+    }
+}
+
+template <typename DyT, int TM>
+__device__ __forceinline__ F4 load_dy4(const BnParamsN &p, const DyT *dy, int64_t pix, int c0) {
+    if (TM) {
+        const size_t o = tm_index(p, pix, c0);
+        F4 d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d.v[i] = (float)dy[o + (size_t)i * p.W];
+        return d;
+    }
+    return load4(dy + pix * p.C + c0);
 }
 
 template <typename XT, typename DyT, int TM>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_nhwc_kernel(BnParamsN p, const DyT *dy, double *sums) {
     const XT *px = (const XT *)p.x;
-    const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
-    const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
-    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
-    const float m = p.mean[c] - (p.shift ? p.shift[c] : 0.f), is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
-    float s = 0.f, q = 0.f;
+    const int C = p.C;
+    NHWC_THREAD_SETUP(p.P);
+    float m[4], is[4], g[4], be[4], s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m[i] = p.mean[c0 + i] - (p.shift ? p.shift[c0 + i] : 0.f);
+        is[i] = p.invstd[c0 + i]; g[i] = p.gamma[c0 + i]; be[i] = p.beta[c0 + i];
+    }
     for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
-        const float xh = ((float)px[pix * C + c] - m) * is;
-        const float y = fmaf(xh, g, be);
-        const float d = (y > p.lo && y < p.hi)
-                            ? (float)dy[TM ? tm_index(p, pix, c) : (size_t)(pix * C + c)] : 0.f;
-        s += d;
-        q += d * xh;
+        const F4 v = load4(px + pix * C + c0);
+        const F4 dv = load_dy4<DyT, TM>(p, dy, pix, c0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (v.v[i] - m[i]) * is[i];
+            const float y = fmaf(xh, g[i], be[i]);
+            const float d = (y > p.lo && y < p.hi) ? dv.v[i] : 0.f;
+            s[i] += d;
+            q[i] += d * xh;
+        }
     }
     nhwc_block_atomics(s, q, C, sums);
 }
@@ -238,19 +304,28 @@ template <typename XT, typename DyT, int TM>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_nhwc_kernel(BnParamsN p, const DyT *dy, const double *sums,
                                                                     double n, int training, XT *dx) {
     const XT *px = (const XT *)p.x;
-    const int C = p.C, PL = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
-    const int64_t per = (p.P + gridDim.x - 1) / gridDim.x;
-    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < p.P ? p0 + per : p.P;
-    const float m = p.mean[c] - (p.shift ? p.shift[c] : 0.f), is = p.invstd[c], g = p.gamma[c], be = p.beta[c];
-    const float k1 = training ? (float)(sums[2 * c] / n) : 0.f;
-    const float k2 = training ? (float)(sums[2 * c + 1] / n) : 0.f;
-    const float gi = g * is;
+    const int C = p.C;
+    NHWC_THREAD_SETUP(p.P);
+    float m[4], is[4], g[4], be[4], k1[4], k2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m[i] = p.mean[c0 + i] - (p.shift ? p.shift[c0 + i] : 0.f);
+        is[i] = p.invstd[c0 + i]; g[i] = p.gamma[c0 + i]; be[i] = p.beta[c0 + i];
+        k1[i] = training ? (float)(sums[2 * (c0 + i)] / n) : 0.f;
+        k2[i] = training ? (float)(sums[2 * (c0 + i) + 1] / n) : 0.f;
+    }
     for (int64_t pix = p0 + pl; pix < p1; pix += PL) {
-        const float xh = ((float)px[pix * C + c] - m) * is;
-        const float y = fmaf(xh, g, be);
-        const float d = (y > p.lo && y < p.hi)
-                            ? (float)dy[TM ? tm_index(p, pix, c) : (size_t)(pix * C + c)] : 0.f;
-        dx[pix * C + c] = (XT)(gi * (d - k1 - xh * k2));
+        const F4 v = load4(px + pix * C + c0);
+        const F4 dv = load_dy4<DyT, TM>(p, dy, pix, c0);
+        F4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (v.v[i] - m[i]) * is[i];
+            const float y = fmaf(xh, g[i], be[i]);
+            const float d = (y > p.lo && y < p.hi) ? dv.v[i] : 0.f;
+            o.v[i] = g[i] * is[i] * (d - k1[i] - xh * k2[i]);
+        }
+        store4(dx + pix * C + c0, o);
     }
 }
 
@@ -297,7 +372,7 @@ extern "C" int asr_bn_act_fwd_f32(const void *x, int x_bf16, const float *conv_b
     double *sums = (double *)workspace;
     const int HW = H * W;
     const dim3 grid(C, B);
-    if (channels_last && (C > 256 || 256 % C != 0)) return ASR_EUNSUPPORTED;
+    if (channels_last && (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0)) return ASR_EUNSUPPORTED;
     if (x_bf16 && !channels_last) return ASR_EUNSUPPORTED;   // bf16 input: channels-last only
     const int64_t P = (int64_t)B * HW;
     const int nwg = (int)(P / 64 < 4096 ? (P / 64 > 0 ? P / 64 : 1) : 4096);
@@ -367,7 +442,7 @@ extern "C" int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_b
     hipLaunchKernelGGL(zero_doubles_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, 2 * C);
     if (x_bf16 && !channels_last) return ASR_EUNSUPPORTED;
     if (channels_last) {
-        if (C > 256 || 256 % C != 0) return ASR_EUNSUPPORTED;
+        if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return ASR_EUNSUPPORTED;
         BnParamsN q;
         q.x = x; q.P = (int64_t)B * HW; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma;
         q.beta = beta; q.mean = save_mean; q.invstd = save_invstd; q.shift = conv_bias; q.lo = lo; q.hi = hi;

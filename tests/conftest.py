@@ -11,6 +11,10 @@ for p in (ROOT, PKG):
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+# the tests run small one-off convolution shapes: let MIOpen pick a solver from its
+# heuristics instead of benchmarking every candidate on a fresh box (minutes)
+os.environ.setdefault('MIOPEN_FIND_MODE', 'FAST')
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

@@ -10,7 +10,7 @@ from torch import nn
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('B,C,H,W', [(3, 32, 50, 17), (5, 4, 7, 11), (2, 32, 334, 11)])
+@pytest.mark.parametrize('B,C,H,W', [(3, 32, 50, 17), (5, 4, 7, 11), (2, 32, 334, 11), (2, 6, 9, 5)])
 @pytest.mark.parametrize('training', [True, False])
 @pytest.mark.parametrize('time_major', [False, True])
 @pytest.mark.parametrize('channels_last', [False, True])
@@ -40,7 +40,7 @@ def test_bn_hardtanh_matches_torch(B, C, H, W, training, time_major, channels_la
         xg = xg.contiguous(memory_format=torch.channels_last)
     xg.requires_grad_()
     y = bn_hardtanh(xg, bn, act, time_major=time_major)
-    if channels_last and not time_major:
+    if channels_last and not time_major and C % 4 == 0:     # C = 6: dense-NCHW fallback
         assert y.is_contiguous(memory_format=torch.channels_last)
     dyg = dy.to(dev)
     if time_major:
