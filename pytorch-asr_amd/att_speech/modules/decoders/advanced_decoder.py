@@ -50,7 +50,10 @@ class _SkinnyLinear(torch.autograd.Function):
                 g = cand
                 break
         dyc = dy2.view(g, rows // g, -1)
-        dw = torch.bmm(dyc.transpose(1, 2), x2.view(g, rows // g, -1)).sum(0)
+        if w.size(0) <= 256:
+            dw = torch.bmm(dyc.transpose(1, 2), x2.view(g, rows // g, -1)).sum(0)
+        else:                       # wide outputs (bigram classes) fill the chip as one GEMM
+            dw = dy2.t().mm(x2)
         db = dyc.sum(1).sum(0) if ctx.has_bias else None
         return dx, dw, db
 
