@@ -440,11 +440,15 @@ struct LstmTeamCtl {
     unsigned *err;          // timeout word
     unsigned spin_limit;
     int bt0, nbt;           // first batch tile of this launch, batch tiles in total
+    size_t rows;            // rows of one hbuf / dgbuf plane (>= 32 * nbt)
 };
 
 #define ASR_GLDS_BYTES (4 * 32 * 65 * 4)
 
-template <int KS>
+// NE = batch rows of the tile / 8 (tiles of 16, 24 or 32 rows: fewer rows per workgroup
+// = more workgroups; the host picks the smallest tile whose grid still fits one
+// workgroup per CU).  Rows >= 8*NE of the 32-row MFMA tile are padding.
+template <int KS, int NE>
 __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, LstmTeamCtl ctl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *a_lds = reinterpret_cast<__bf16 *>(smem);                       // KS KiB
@@ -453,12 +457,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     __shared__ int dead_s;
     const int H = p.H, B = p.B, T = p.T;
     const int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
-    const int j0 = jt * 64, b0 = btile * 32, njt = H / 64;
+    const int j0 = jt * 64, b0 = btile * (8 * NE), njt = H / 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int gate = wave >> 1, js = wave & 1;
-    const size_t Bp = (size_t)((B + 63) & ~63);
+    const size_t Bp = ctl.rows;              // rows of an hbuf / dgbuf plane (32 per batch tile)
     unsigned *myctr = ctl.ctr + ((size_t)dir * ctl.nbt + btile) * 32;
     if (tid == 0) dead_s = 0;
+    for (int i = tid; i < 2048; i += 512) h_lds[i] = (__bf16)0.f;       // padding rows stay 0
 
     bf16x8 fb[KS];
     {
@@ -472,12 +477,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
 
     // the thread's four (row, col) elements: row = e*8 + wave, col = lane
     const int col = lane, j = j0 + col;
-    float c[4];
-    __bf16 hq[4];
-    int len[4];
-    size_t gxrow[4];            // offset of (b, dir, gate 0, j) inside one frame of gx
+    float c[NE];
+    __bf16 hq[NE];
+    int len[NE];
+    size_t gxrow[NE];            // offset of (b, dir, gate 0, j) inside one frame of gx
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int b = b0 + e * 8 + wave;
         const int bc = b < B ? b : B - 1;
         c[e] = 0.f;
@@ -491,20 +496,20 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     // (behind the hand-off tile in the wave's in-order vmcnt queue, never in
     // front of the team poll); the outputs nobody inside the launch reads are
     // stored after the team signal, under the hand-off latency.
-    float pgx[4][4];
+    float pgx[NE][4];
     {
         const int t0 = dir == 0 ? 0 : T - 1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < NE; ++e)
 #pragma unroll
             for (int g = 0; g < 4; ++g) pgx[e][g] = p.gx[(size_t)t0 * gxframe + gxrow[e] + (size_t)g * H];
     }
-    float sog[4][4], soh[4], sc[4];
-    bool sact[4];
+    float sog[NE][4], soh[NE], sc[NE];
+    bool sact[NE];
     int st = 0;
     auto bulk_store = [&]() {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int b = b0 + e * 8 + wave;
             if (b < B) {
                 p.y[(((size_t)st * B + b) * 2 + dir) * H + j] = soh[e];
@@ -547,12 +552,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         }
         __syncthreads();
         PSTAMP(1);
-        float ngx[4][4];
+        float ngx[NE][4];
         {
             const int sn = step + 1 < T ? step + 1 : step;
             const int tn = dir == 0 ? sn : T - 1 - sn;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < NE; ++e)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     ngx[e][g] = p.gx[(size_t)tn * gxframe + gxrow[e] + (size_t)g * H];
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         const bool dead = dead_s != 0;
         st = t;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int row = e * 8 + wave;
             sact[e] = t < len[e];
             if (sact[e]) {
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         if (tid == 0) __hip_atomic_fetch_add(myctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bulk_store();       // outputs nobody inside this launch reads: after the signal
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < NE; ++e)
 #pragma unroll
             for (int g = 0; g < 4; ++g) pgx[e][g] = ngx[e][g];
         PSTAMP(5);
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
 #endif
 }
 
-template <int KS>
+template <int KS, int NE>
 __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, LstmTeamCtl ctl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KS4 = 4 * KS;
@@ -630,12 +635,13 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
     __shared__ int dead_s;
     const int H = p.H, B = p.B, T = p.T, H4 = 4 * p.H;
     const int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
-    const int j0 = jt * 64, b0 = btile * 32, njt = H / 64;
+    const int j0 = jt * 64, b0 = btile * (8 * NE), njt = H / 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kq = wave >> 1, js = wave & 1;
-    const size_t Bp = (size_t)((B + 63) & ~63);
+    const size_t Bp = ctl.rows;              // rows of an hbuf / dgbuf plane (32 per batch tile)
     unsigned *myctr = ctl.ctr + ((size_t)dir * ctl.nbt + btile) * 32;
     if (tid == 0) dead_s = 0;
+    for (int i = tid; i < 8192; i += 512) dg_lds[i] = (__bf16)0.f;      // padding rows stay 0
 
     bf16x8 fb[KS];
     {
@@ -648,10 +654,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
         p.dgbuf, 0, (int)(2 * 2 * Bp * H4 * 2), 0x00020000);
 
     const int col = lane, j = j0 + col;
-    float dcarry[4];
-    int len[4], bcl[4];
+    float dcarry[NE];
+    int len[NE], bcl[NE];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int b = b0 + e * 8 + wave;
         dcarry[e] = 0.f;
         len[e] = b < B ? p.lens[b] : 0;
@@ -661,12 +667,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
     // operands of the cell backward at frame t: saved gates, dy, and the cell
     // state the step started from (c of the neighbouring frame, raw); c_t itself
     // is the neighbour value fetched one step earlier
-    struct Pre { float g[4][4], cp[4], dy[4]; };
+    struct Pre { float g[NE][4], cp[NE], dy[NE]; };
     auto fetch = [&](int t, Pre &q) {
         const int tp = dir == 0 ? t - 1 : t + 1;
         const int tpc = tp < 0 ? 0 : (tp >= T ? T - 1 : tp);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const size_t gsave = ((((size_t)t * 2 + dir) * B + bcl[e]) * 4) * H + j;
 #pragma unroll
             for (int g = 0; g < 4; ++g) q.g[e][g] = p.gates[gsave + (size_t)g * H];
@@ -676,18 +682,18 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
         }
     };
     Pre cur;
-    float pcs[4];
+    float pcs[NE];
     {
         const int t0 = dir == 0 ? T - 1 : 0;
         fetch(t0, cur);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pcs[e] = p.csave[(((size_t)t0 * 2 + dir) * B + bcl[e]) * H + j];
+        for (int e = 0; e < NE; ++e) pcs[e] = p.csave[(((size_t)t0 * 2 + dir) * B + bcl[e]) * H + j];
     }
-    __bf16 sod[4][4];
+    __bf16 sod[NE][4];
     int st = 0;
     auto bulk_store = [&]() {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int b = b0 + e * 8 + wave;
             if (b < B) {
                 __bf16 *dgo = p.dgates + (((size_t)st * B + b) * 2 + dir) * H4 + j;
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
         st = t;
         const int tp = dir == 0 ? t - 1 : t + 1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int row = e * 8 + wave;
             float od[4];
             if (t < len[e]) {
@@ -815,7 +821,7 @@ inline void zero_async(void *p, size_t bytes, hipStream_t s) {
     hipLaunchKernelGGL(zero_bytes_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t *)p, n);
 }
 
-inline int64_t ctl_bytes(int B) { return ((int64_t)2 * ((B + 31) / 32) * 128 + 256 + 255) / 256 * 256; }
+inline int64_t ctl_bytes(int B) { return ((int64_t)2 * ((B + 15) / 16) * 128 + 256 + 255) / 256 * 256; }
 
 // persistent path on unless ASR_LSTM_PERSIST=0 (A/B switch for tests and profiling)
 inline bool persist_enabled() {
@@ -833,12 +839,28 @@ inline int cu_count() {
 // Launch a persistent kernel over all batch tiles, at most one workgroup per CU
 // per launch (every team of a launch must be resident).  Returns false if the
 // shape cannot run persistently (caller falls back to one launch per step).
+// rows of one hbuf / dgbuf plane: 32 per batch tile of the smallest tile (16 rows), or
+// the 64-row padding of the per-step kernels, whichever is larger
+inline int64_t plane_rows(int B) {
+    const int64_t a = (int64_t)(B + 63) / 64 * 64, b = (int64_t)((B + 15) / 16) * 32;
+    return a > b ? a : b;
+}
+
 template <typename P>
-bool launch_persist(void (*kern)(P, LstmTeamCtl), const P &p, int B, int H, size_t lds_need,
-                    unsigned *ctl_words, hipStream_t s) {
-    const int njt = H / 64, nbt = (B + 31) / 32;
+bool launch_persist(void (*const kerns[3])(P, LstmTeamCtl), const P &p, int B, int H,
+                    size_t lds_need, unsigned *ctl_words, hipStream_t s) {
+    const int njt = H / 64;
     const int cus = cu_count();
     if ((H % 64) != 0 || njt < 1 || cus < 2 * njt || lds_need > 160 * 1024) return false;
+    // batch-tile rows: the smallest of 16 / 24 / 32 whose whole grid is one launch with one
+    // workgroup per CU (more workgroups = less work on each one's critical path); 32-row
+    // tiles in several launches when the batch is too large for that
+    int ne = 4;
+    for (int cand = 2; cand <= 4; ++cand)
+        if (2 * njt * ((B + 8 * cand - 1) / (8 * cand)) <= cus) { ne = cand; break; }
+    void (*kern)(P, LstmTeamCtl) = kerns[ne - 2];
+    if (!kern) return false;
+    const int nbt = (B + 8 * ne - 1) / (8 * ne);
     const size_t lds = lds_need > 84 * 1024 ? lds_need : 84 * 1024;     // > half the LDS: 1 workgroup per CU
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
@@ -849,6 +871,7 @@ bool launch_persist(void (*kern)(P, LstmTeamCtl), const P &p, int B, int H, size
     ctl.err = ctl_words;
     ctl.spin_limit = 1u << 18;
     ctl.nbt = nbt;
+    ctl.rows = (size_t)plane_rows(B);
     for (int bt0 = 0; bt0 < nbt; bt0 += max_bt) {
         ctl.bt0 = bt0;
         const int n = nbt - bt0 < max_bt ? nbt - bt0 : max_bt;
@@ -864,7 +887,7 @@ extern "C" int64_t asr_lstm_workspace_bytes(int B, int H) {
     // forward: hbuf bf16 [2][2][Bp][H] + cbuf f32 [2][B][H] + packed W_hh
     // backward: dgbuf bf16 [2][2][Bp][4H] + dcbuf f32 [2][B][H] + packed W_hhᵀ (larger)
     // + team counters of the persistent kernels: [2 dir][ceil(B/32)] x 128 B and a timeout word
-    const int64_t Bp = (B + 63) / 64 * 64;
+    const int64_t Bp = plane_rows(B);
     return (int64_t)2 * 2 * Bp * 4 * H * 2 + (int64_t)2 * B * H * 4 +
            (int64_t)2 * 4 * H * H * 2 + 256 + ctl_bytes(B);
 }
@@ -882,7 +905,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmFwdParams p;
-    const size_t Bp = (size_t)(B + 63) / 64 * 64;
+    const size_t Bp = (size_t)plane_rows(B);
     const size_t hbytes = (size_t)2 * 2 * Bp * H * 2, cbytes = (size_t)2 * B * H * 4;
     __bf16 *wpack = (__bf16 *)((char *)workspace + hbytes + cbytes);
     p.gx = gx; p.whh = wpack; p.lens = lens;
@@ -902,11 +925,12 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
     if (persist_enabled()) {
         unsigned *ctl_words = (unsigned *)((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B));
         zero_async(ctl_words, (size_t)ctl_bytes(B), s);
-        void (*pk)(LstmFwdParams, LstmTeamCtl) = nullptr;
-#define ASR_PICK(KSV) if (H == 16 * KSV) pk = lstm_fwd_persist_kernel<KSV>;
+        void (*pk[3])(LstmFwdParams, LstmTeamCtl) = {nullptr, nullptr, nullptr};
+#define ASR_PICK(KSV) if (H == 16 * KSV) { pk[0] = lstm_fwd_persist_kernel<KSV, 2>; \
+        pk[1] = lstm_fwd_persist_kernel<KSV, 3>; pk[2] = lstm_fwd_persist_kernel<KSV, 4>; }
         ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32)   // 48: W_hh slice spills
 #undef ASR_PICK
-        if (pk && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + ASR_GLDS_BYTES + 4096,
+        if (pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + ASR_GLDS_BYTES + 4096,
                                  ctl_words, s))
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
@@ -941,7 +965,7 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const voi
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmBwdParams p;
-    const size_t Bp = (size_t)(B + 63) / 64 * 64;
+    const size_t Bp = (size_t)plane_rows(B);
     const size_t dbytes = (size_t)2 * 2 * Bp * 4 * H * 2, cbytes = (size_t)2 * B * H * 4;
     __bf16 *wpack = (__bf16 *)((char *)workspace + dbytes + cbytes);
     p.dy = dy; p.dy_shared = dy_shared; p.whhT = wpack; p.lens = lens;
@@ -957,11 +981,12 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const voi
     if (persist_enabled()) {
         unsigned *ctl_words = (unsigned *)((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B));
         zero_async(ctl_words, (size_t)ctl_bytes(B), s);
-        void (*pk)(LstmBwdParams, LstmTeamCtl) = nullptr;
-#define ASR_PICK(KSV) if (H == 16 * KSV) pk = lstm_bwd_persist_kernel<KSV>;
+        void (*pk[3])(LstmBwdParams, LstmTeamCtl) = {nullptr, nullptr, nullptr};
+#define ASR_PICK(KSV) if (H == 16 * KSV) { pk[0] = lstm_bwd_persist_kernel<KSV, 2>; \
+        pk[1] = lstm_bwd_persist_kernel<KSV, 3>; pk[2] = lstm_bwd_persist_kernel<KSV, 4>; }
         ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24)
 #undef ASR_PICK
-        if (pk && launch_persist(pk, p, B, H, (size_t)(H / 4) * 1024 + ASR_GLDS_BYTES + 16384,
+        if (pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 4) * 1024 + ASR_GLDS_BYTES + 16384,
                                  ctl_words, s))
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
