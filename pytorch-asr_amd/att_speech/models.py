@@ -39,15 +39,13 @@ class SpeechModel(nn.Module):
     def decode(self, features, feature_lens, speakers, texts=None,
                text_lens=None, encoder_args=None, decoder_args=None,
                ivectors=None, **kwargs):
-        encoder_args = {} if encoder_args is None else encoder_args
-        decoder_args = {} if decoder_args is None else decoder_args
-        encoder_args.update(kwargs)
-        decoder_args.update(kwargs)
+        """(:63-93) extra keyword arguments go to BOTH halves, on top of the
+        per-half dictionaries; runs without autograd."""
+        enc_kw = dict(encoder_args or {}, **kwargs)
+        dec_kw = dict(decoder_args or {}, **kwargs)
         with torch.no_grad():
-            encoded, encoded_lens = self.encoder(
-                features, feature_lens, speakers, ivectors, **encoder_args)
-            return self.decoder.decode(encoded, encoded_lens, texts, text_lens,
-                                       spkids=speakers, **decoder_args)
+            enc, enc_lens = self.encoder(features, feature_lens, speakers, ivectors, **enc_kw)
+            return self.decoder.decode(enc, enc_lens, texts, text_lens, spkids=speakers, **dec_kw)
 
     def get_parameters_for_optimizer(self):
         return itertools.chain(self.encoder.get_parameters_for_optimizer(),
