@@ -195,7 +195,8 @@ int asr_lattice_grouped_forward_f32(
  * the sequential part of BatchRNN (modules/encoders/encoder_utils.py:55-124:
  * nn.LSTM(bidirectional=True, bias=False) applied to a PackedSequence).
  * The caller supplies the input projection of every frame,
- *   gx [T,B,2,4H] f32 = x · W_ihᵀ   (direction-major, gate order i,f,g,o),
+ *   gx [T,B,2,4H] f32, or bf16 with gx_bf16 != 0 (what a bf16 GEMM emits; halves its
+ *      1.75 GB output at B=512) = x · W_ihᵀ   (direction-major, gate order i,f,g,o),
  * and the recurrent weights as bf16 (MFMA operands; accumulation, gates and
  * the cell state are fp32):  whh [2,4H,H] for the forward pass,
  * whhT [2,H,4H] (transposed) for the backward pass.
@@ -220,7 +221,7 @@ int asr_lattice_grouped_forward_f32(
  */
 int64_t asr_lstm_workspace_bytes(int B, int H);
 
-int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
+int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *whh_bf16,
                             const int32_t *lens, int T, int B, int H,
                             float *y, void *y_bf16, float *gates, float *csave,
                             void *workspace, int64_t workspace_bytes,

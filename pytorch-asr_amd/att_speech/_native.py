@@ -47,7 +47,7 @@ _SIGNATURES = {
     'asr_lattice_grouped_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i] + [_vp] * 8 +
                                         [_f, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_workspace_bytes': (_i64, [_i, _i]),
-    'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_bn_act_workspace_bytes': (_i64, [_i]),
     'asr_bn_act_fwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
@@ -239,9 +239,9 @@ def argmax_rows(x):
 
 
 def lstm_bidir_fwd(gx, whh_bf16, lens):
-    """asr_lstm_bidir_fwd_bf16: gx [T,B,2,4H] f32, whh [2,4H,H] bf16, lens [B] i32
+    """asr_lstm_bidir_fwd_bf16: gx [T,B,2,4H] f32 or bf16, whh [2,4H,H] bf16, lens [B] i32
     -> (y [T,B,2,H] f32, y_bf16 [2,T+2,B,H], gates [T,2,B,4,H], csave [T,2,B,H])."""
-    gx = _dev(gx, torch.float32, 'gx')
+    gx = _dev(gx, gx.dtype if gx.dtype == torch.bfloat16 else torch.float32, 'gx')
     whh_bf16 = _dev(whh_bf16, torch.bfloat16, 'whh')
     lens = _dev(lens, torch.int32, 'lens')
     T, B, _, H4 = gx.shape
@@ -253,7 +253,8 @@ def lstm_bidir_fwd(gx, whh_bf16, lens):
     csave = torch.empty((T, 2, B, H), dtype=torch.float32, device=gx.device)
     nbytes = L.asr_lstm_workspace_bytes(B, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=gx.device)
-    check(L.asr_lstm_bidir_fwd_bf16(_p(gx), _p(whh_bf16), _p(lens), T, B, H, _p(y),
+    check(L.asr_lstm_bidir_fwd_bf16(_p(gx), int(gx.dtype == torch.bfloat16), _p(whh_bf16),
+                                    _p(lens), T, B, H, _p(y),
                                     _p(ybf), _p(gates), _p(csave), _p(ws), nbytes,
                                     _stream()), 'asr_lstm_bidir_fwd_bf16')
     return y, ybf, gates, csave

@@ -6,6 +6,8 @@ Replaces the vendor LSTM behind `BatchRNN.rnn` (reference
 modules/encoders/encoder_utils.py:78,100) while keeping the nn.LSTM parameter
 tensors (weight_ih_l0, weight_hh_l0, *_reverse), so state_dict keys and
 optimizers are unchanged."""
+import os
+
 import torch
 
 from att_speech import _native
@@ -46,7 +48,12 @@ class BiLSTMFunction(torch.autograd.Function):
         H = w_hh_f.shape[1]
         xb = x.reshape(T * B, F).to(torch.bfloat16)
         w_ih = torch.cat([w_ih_f, w_ih_r], 0).to(torch.bfloat16)        # [2*4H, F]
-        gx = _mm_f32(xb, w_ih.t()).view(T, B, 2, 4 * H)
+        # x·W_ih: fp32 accumulation in the GEMM, stored once as bf16 (ASR_GX_FP32=1 keeps
+        # fp32): the [T*B, 8H] product is 1.75 GB in fp32 at B=512 and its write bounds the GEMM
+        if os.environ.get('ASR_GX_FP32', '0') == '1':
+            gx = _mm_f32(xb, w_ih.t()).view(T, B, 2, 4 * H)
+        else:
+            gx = torch.mm(xb, w_ih.t()).view(T, B, 2, 4 * H)
         whh = torch.stack([w_hh_f, w_hh_r], 0).to(torch.bfloat16).contiguous()
         y, ybf, gates, csave = _native.lstm_bidir_fwd(gx, whh, lens_dev)
         ctx.save_for_backward(xb, lens_dev, w_ih, whh, ybf, gates, csave)
@@ -61,7 +68,10 @@ class BiLSTMFunction(torch.autograd.Function):
         whhT = whh.transpose(1, 2).contiguous()                          # [2,H,4H]
         dgb = _native.lstm_bidir_bwd(dy.contiguous(), whhT, lens_dev, gates, csave)
         dg2 = dgb.view(T * B, 2 * 4 * H)                                 # bf16
-        dx = _mm_f32(dg2, w_ih).view(T, B, F)
+        # K-major second operand: the library's kernel for it is faster here (probe 0.38 vs
+        # 0.44 ms) than the one it picks for the row-major [8H, F] weight; the transpose is
+        # a 1.6 MB copy
+        dx = _mm_f32(dg2, w_ih.t().contiguous().t()).view(T, B, F)
         # Weight gradients: [4H.. x TB] x [TB x F|H] with TB = T*B frames and a small
         # output.  As one GEMM the library fills 100-170 of 256 CUs (0.79 / 1.06 ms
         # at TB = 171k); split over G chunks of frames as a batched GEMM plus a sum

@@ -80,8 +80,17 @@ __device__ __forceinline__ void lstm_cell_bwd(const float g[4], float cs, float 
     dcout = dc * gf;
 }
 
+// x·W_ih term: fp32, or the bf16 the input-projection GEMM emits (halves its 1.75 GB
+// output at B=512 and this kernel's reads; fp32 accumulation either way)
+template <int GXB>
+__device__ __forceinline__ float load_gx(const void *gx, size_t i) {
+    if constexpr (GXB) return (float)((const __bf16 *)gx)[i];
+    else return ((const float *)gx)[i];
+}
+
 struct LstmFwdParams {
-    const float *gx;        // [T,B,2,4H] x·W_ihᵀ, gate order i,f,g,o
+    const void *gx;         // [T,B,2,4H] x·W_ihᵀ, gate order i,f,g,o; float or (gx_bf16) __bf16
+    int gx_bf16;
     const __bf16 *whh;      // fragment-major pack of [2*4 (dir,gate)][H rows][H cols]
     const int32_t *lens;    // [B]
     int T, B, H;
@@ -133,7 +142,7 @@ __global__ void lstm_pack_kernel(const __bf16 *in, __bf16 *out, int nmat, int ro
 // the h_{t-1} tile — needed by all four waves — is staged once through LDS.
 // BT = 2 halves the W_hh re-reads per step (the kernel is bound by operand
 // fetch from L2 / Infinity Cache, not by the MFMAs).
-template <int KS, int BT>
+template <int KS, int BT, int GXB>
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
 #ifdef ASR_LSTM_STAMPS
     unsigned long long stamp[4];
@@ -188,9 +197,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
         const int b = b0 + (idx >> 5), j = j0 + (idx & 31);
         const int bc = b < B ? b : B - 1;
         pact[e] = b < B && t < p.lens[bc];
-        const float *gxp = p.gx + (((size_t)t * B + bc) * 2 + dir) * 4 * H + j;
+        const size_t gxo = (((size_t)t * B + bc) * 2 + dir) * 4 * H + j;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pgx[e][g] = gxp[g * H];
+        for (int g = 0; g < 4; ++g) pgx[e][g] = load_gx<GXB>(p.gx, gxo + (size_t)g * H);
         pc[e] = p.cbuf[((size_t)dir * B + bc) * H + j];
     }
     __syncthreads();
@@ -448,7 +457,7 @@ struct LstmTeamCtl {
 // NE = batch rows of the tile / 8 (tiles of 16, 24 or 32 rows: fewer rows per workgroup
 // = more workgroups; the host picks the smallest tile whose grid still fits one
 // workgroup per CU).  Rows >= 8*NE of the 32-row MFMA tile are padding.
-template <int KS, int NE>
+template <int KS, int NE, int GXB>
 __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, LstmTeamCtl ctl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *a_lds = reinterpret_cast<__bf16 *>(smem);                       // KS KiB
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
 #pragma unroll
         for (int e = 0; e < NE; ++e)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pgx[e][g] = p.gx[(size_t)t0 * gxframe + gxrow[e] + (size_t)g * H];
+            for (int g = 0; g < 4; ++g) pgx[e][g] = load_gx<GXB>(p.gx, (size_t)t0 * gxframe + gxrow[e] + (size_t)g * H);
     }
     float sog[NE][4], soh[NE], sc[NE];
     bool sact[NE];
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
             for (int e = 0; e < NE; ++e)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    ngx[e][g] = p.gx[(size_t)tn * gxframe + gxrow[e] + (size_t)g * H];
+                    ngx[e][g] = load_gx<GXB>(p.gx, (size_t)tn * gxframe + gxrow[e] + (size_t)g * H);
         }
         {
             f32x16 acc;
@@ -892,7 +901,7 @@ extern "C" int64_t asr_lstm_workspace_bytes(int B, int H) {
            (int64_t)2 * 4 * H * H * 2 + 256 + ctl_bytes(B);
 }
 
-extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
+extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *whh_bf16,
                                        const int32_t *lens, int T, int B, int H,
                                        float *y, void *y_bf16, float *gates,
                                        float *csave,
@@ -908,7 +917,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
     const size_t Bp = (size_t)plane_rows(B);
     const size_t hbytes = (size_t)2 * 2 * Bp * H * 2, cbytes = (size_t)2 * B * H * 4;
     __bf16 *wpack = (__bf16 *)((char *)workspace + hbytes + cbytes);
-    p.gx = gx; p.whh = wpack; p.lens = lens;
+    p.gx = gx; p.gx_bf16 = gx_bf16; p.whh = wpack; p.lens = lens;
     p.T = T; p.B = B; p.H = H;
     p.hbuf = (__bf16 *)workspace;
     p.cbuf = (float *)((char *)workspace + hbytes);
@@ -926,8 +935,11 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
         unsigned *ctl_words = (unsigned *)((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B));
         zero_async(ctl_words, (size_t)ctl_bytes(B), s);
         void (*pk[3])(LstmFwdParams, LstmTeamCtl) = {nullptr, nullptr, nullptr};
-#define ASR_PICK(KSV) if (H == 16 * KSV) { pk[0] = lstm_fwd_persist_kernel<KSV, 2>; \
-        pk[1] = lstm_fwd_persist_kernel<KSV, 3>; pk[2] = lstm_fwd_persist_kernel<KSV, 4>; }
+#define ASR_PICK(KSV) if (H == 16 * KSV) {                                                     \
+        if (gx_bf16) { pk[0] = lstm_fwd_persist_kernel<KSV, 2, 1>; pk[1] = lstm_fwd_persist_kernel<KSV, 3, 1>; \
+                       pk[2] = lstm_fwd_persist_kernel<KSV, 4, 1>; }                                \
+        else { pk[0] = lstm_fwd_persist_kernel<KSV, 2, 0>; pk[1] = lstm_fwd_persist_kernel<KSV, 3, 0>; \
+               pk[2] = lstm_fwd_persist_kernel<KSV, 4, 0>; } }
         ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32)   // 48: W_hh slice spills
 #undef ASR_PICK
         if (pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + ASR_GLDS_BYTES + 4096,
@@ -941,7 +953,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const float *gx, const void *whh_bf16,
     const dim3 grid(H / 32, (B + 32 * bt - 1) / (32 * bt), 2);
     void (*kern)(LstmFwdParams) = nullptr;
 #define ASR_PICK(KSV)                                                              \
-    if (H == 16 * KSV) kern = bt == 2 ? lstm_fwd_step_kernel<KSV, 2> : lstm_fwd_step_kernel<KSV, 1>;
+    if (H == 16 * KSV) kern = gx_bf16 ? lstm_fwd_step_kernel<KSV, 1, 1> : lstm_fwd_step_kernel<KSV, 1, 0>;
     ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32) ASR_PICK(48)
 #undef ASR_PICK
     if (!kern) return ASR_EUNSUPPORTED;       // hidden sizes built: 64,128,256,320,384,512,768
