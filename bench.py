@@ -291,10 +291,11 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'WSJ %s-char CTC (egs/wsj/yamls/%s.yaml shapes), DeepSpeech2 '
-                                   'conv+4xBiLSTM-320 encoder + FSTDecoder, fwd+bwd+Adam, '
+                                   'conv+4xBiLSTM-320 encoder + FSTDecoder, fwd+bwd+%sAdam, '
                                    'synthetic 40-dim x %d-frame fbank'
                                    % ('mono' if order == 1 else 'bi',
-                                      a.workload or ('ctc' if order == 1 else 'ctc_bi'), T),
+                                      a.workload or ('ctc' if order == 1 else 'ctc_bi'),
+                                      '' if a.no_hooks else 'GradientClipping+PolyakDecay+', T),
                        'batch_per_gpu': B, 'global_batch': B * world, 'frames': T,
                        'classes': C, 'parallelism': 'dp%d' % world,
                        'final_loss': float(loss)},
