@@ -84,6 +84,8 @@ def _run_native(gx, whh, lens, dy, persist):
 
 
 @pytest.mark.parametrize('T,B,H,reps', [
+    (1, 1, 64, 1),             # a single frame, a single utterance
+    (2, 3, 64, 1),
     (23, 7, 64, 1),            # one workgroup per team, ragged batch tile
     (61, 45, 128, 1),          # two-workgroup teams
     (150, 96, 320, 1),         # five-workgroup teams (the encoder's hidden size)
