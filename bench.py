@@ -147,16 +147,21 @@ def cpu_baseline(T, order, seconds_budget=15.0):
 
 def pmc_traffic(order, B, T):
     """HBM bytes per lattice launch from the PMC passes committed under profiles/
-    (r01_pmc_lattice_fetch_write.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of
-    tools/bench_lattice.py at B=512, T'=334; FETCH_SIZE reads half of a 4 B/lane coalesced
+    (r01_pmc_step_fetch_write.json / r01_pmc_lattice_fetch_write.json: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of bench.py / tools/bench_lattice.py at B=512, T'=334; FETCH_SIZE reads half of a 4 B/lane coalesced
     stream on gfx950 - calibrated on log_softmax_fwd - so traffic = 2*FETCH + WRITE).
     bench.py cannot collect counters itself; the figure applies to the measured shape only."""
     if B != 512 or T != 1000:
         return None
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_lattice_fetch_write.json')
-    try:
-        pmc = json.load(open(path))
-        k = 'lattice_fwbw_sl_kernel<3, 8, 1>' if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>'
+    k = 'lattice_fwbw_sl_kernel<3, 8, 1>' if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>'
+    try:    # passes over bench.py itself (the lattice launch inside the training step)
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_step_fetch_write.json')))
+        e = pmc['kernels'][k]
+        return (2 * e['fetch_KB'] + e['write_KB']) * 1024.0
+    except (OSError, KeyError, ValueError):
+        pass
+    try:    # passes over tools/bench_lattice.py (same shapes, kernel alone)
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_lattice_fetch_write.json')))
         return (2 * pmc['FETCH_SIZE'][k]['mean_KB'] + pmc['WRITE_SIZE'][k]['mean_KB']) * 1024.0
     except (OSError, KeyError, ValueError):
         return None
