@@ -30,6 +30,7 @@ struct FwbwParams {
     float *logZ, *grad, *logZ_bwd;
     float *alphas;  // [T,B,N]
     int *skip;      // [B] or null: utterances already done by the band kernel
+    int *split;     // [B] (FL == 2): 1 = posteriors left in ws for lattice_scatter_kernel
 };
 
 // KR > 0: every thread owns ONE state (N <= blockDim) and keeps its <= KR
@@ -290,8 +291,10 @@ __device__ __forceinline__ void lattice_fwbw_mitm_body(const FwbwParams &p, floa
     const size_t tstride = (size_t)p.B * C;
     const float *lp_b = p.lp + (size_t)b * C;
     float *grad_b = p.grad + (size_t)b * C;
-    const size_t astride = (size_t)p.B * N;
-    float *ws_b = p.alphas + (size_t)b * N;
+    // workspace rows are [B, H] like the state-labelled kernel's (a mixed batch has
+    // both kinds of workgroup in one launch: their regions must not overlap)
+    const size_t astride = (size_t)p.B * H;
+    float *ws_b = p.alphas + (size_t)b * H;
     const float half_inf = p.neg_inf * 0.5f;
     const bool own = n < N;
 
@@ -544,11 +547,18 @@ __device__ __forceinline__ float dpp_wave_sum(float v) {
 template <int K, int D, int FL>
 __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
     // FL == 1: C <= H, the per-step row flush is one store per lane;
-    // FL == 0: runtime flush loop (large C, bandwidth-bound regime).
+    // FL == 0: runtime flush loop (large C, bandwidth-bound regime);
+    // FL == 2: split scatter — phase 1 leaves the state posteriors gamma_f[n] in the
+    //          workspace (in place of the value it consumed: slot f for f < m, slot f+1
+    //          for f >= m) and lattice_scatter_kernel sums them per class afterwards at
+    //          full occupancy, so nothing but the recurrence sits on the sequential chain.
     extern __shared__ float smem[];
     typedef unsigned int u32;
     const int b = blockIdx.x;
-    if (p.skip && p.skip[b]) return;                  // done by lattice_fwbw_band_kernel
+    if (p.skip && p.skip[b]) {                        // done by lattice_fwbw_band_kernel
+        if (FL == 2 && threadIdx.x == 0) p.split[b] = 0;
+        return;
+    }
     const int H = blockDim.x >> 1;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >= (unsigned)H ? 1 : 0);
     const int n = threadIdx.x - grp * H;
@@ -577,9 +587,11 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
             if (w_in[n * Kin + k] > half_inf && il_in[n * Kin + k] != label) ok = false;
     }
     if (!__syncthreads_and(ok)) {
+        if (FL == 2 && threadIdx.x == 0) p.split[b] = 0;
         lattice_fwbw_mitm_body<4, 8>(p, smem);
         return;
     }
+    if (FL == 2 && threadIdx.x == 0) p.split[b] = 1;
 
     int len = p.lens[b];
     len = len < 0 ? 0 : (len > p.T ? p.T : len);
@@ -589,9 +601,10 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
     const size_t tstride = (size_t)p.B * C;
     float *grad_b = p.grad + (size_t)b * C;
 
-    for (int t = len; t < p.T; ++t)                  // fst_utils.py:448
-        for (int c = threadIdx.x; c < C; c += blockDim.x)
-            grad_b[(size_t)t * tstride + c] = 0.f;
+    if (FL != 2)
+        for (int t = len; t < p.T; ++t)              // fst_utils.py:448
+            for (int c = threadIdx.x; c < C; c += blockDim.x)
+                grad_b[(size_t)t * tstride + c] = 0.f;
 
     // ---- buffer resources: every global access of the scan goes through a
     // bounds-checked raw buffer with a per-lane 32-bit byte offset, so the
@@ -721,7 +734,7 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
         float fl = 0.f;
         const int ci = n < C ? n : 0;
         if (PH == 1 && FL == 1) fl = row[rf + ci];
-        if (PH == 1) {
+        if (PH == 1 && FL != 2) {
             // keep the LDS reads ahead of the DPP reduction: it runs in their shadow
             __builtin_amdgcn_sched_barrier(0);
             side_accumulate();
@@ -752,7 +765,9 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
             float gam = __builtin_amdgcn_exp2f((isB ? breg : val1) + wv - logZ2);
             if (!own || !act) gam = 0.f;
             gprev = gam;
-            if (FL == 1) {
+            if (FL == 2) {
+                st(wsR, (SOLO == 0 || act) ? gcur : OOB, gam);
+            } else if (FL == 1) {
             } else if (do_flush) {
                 for (int c = n; c < C; c += H) {
                     st(gradR, gcur + (u32)(c - n) * 4u, row[rf + c]);
@@ -766,6 +781,7 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
     };
     // phase-1 drain step: side work only
     auto drain = [&](bool do_flush) {
+        if (FL == 2) return;
         const int ci = n < C ? n : 0;
         side_accumulate();
         gprev = 0.f;
@@ -872,8 +888,9 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
 
     SL_STAMP(2);
     // ================= phase 1 ============================================
-    const u32 gstep = estep;
-    gcur = n4 + (u32)fG1 * ts4;                   // row flushed at step 0 (masked off)
+    // FL == 2: gcur walks the workspace slots this group loads (gamma goes back in place)
+    const u32 gstep = FL == 2 ? wstep : estep;
+    gcur = FL == 2 ? woff(sL1) : n4 + (u32)fG1 * ts4;   // FL != 2: row flushed at step 0 (masked off)
 #pragma unroll
     for (int u = 0; u < D; ++u)
         if (u < r) {
@@ -935,6 +952,71 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
         for (int i = 0; i < 4; ++i) o[i] = (float)(stamp[i + 1] - stamp[i]);
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// Second half of the split scatter (lattice_fwbw_sl_kernel<.., 2>): per frame and
+// utterance, grad[f,b,c] = sum_{n: label n = c} gamma_f[n] with gamma read from the
+// workspace (slot f for f < len/2, slot f+1 above), zeros for f >= len
+// (fst_utils.py:448).  One 4-wave workgroup per utterance and chunk of 4*FPW
+// frames; a wave takes one frame per iteration: H/64 coalesced loads per lane,
+// the label of state 0 (the blank of a CTC chain, shared by half the states) is
+// summed with DPP, the others with LDS float adds into the wave's own bins.
+// ---------------------------------------------------------------------------
+template <int NJ, int FPW>
+__global__ __launch_bounds__(256) void lattice_scatter_kernel(FwbwParams p) {
+    extern __shared__ float smem[];
+    const int b = blockIdx.x;
+    if (!p.split[b]) return;
+    const int N = p.N, C = p.C, H = NJ * 64;
+    const int Cpad = (C + 3) & ~3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *bins = smem + wave * Cpad;
+    const int g = (p.Bg == 1) ? 0 : b;
+    const int32_t *il_in = p.il_in + (size_t)g * N * p.Kin;
+    int lab[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = lane + 64 * j;
+        lab[j] = n < N ? il_in[(size_t)n * p.Kin] : -1;
+    }
+    const int l0 = __builtin_amdgcn_readfirstlane(lab[0]);
+    int len = p.lens[b];
+    len = len < 0 ? 0 : (len > p.T ? p.T : len);
+    const int m = len >> 1;
+    for (int c = lane; c < Cpad; c += 64) bins[c] = 0.f;
+    const int f0 = blockIdx.y * (4 * FPW) + wave;
+    float v[FPW][NJ];
+#pragma unroll
+    for (int it = 0; it < FPW; ++it) {
+        const int f = f0 + 4 * it;
+        const int slot = f < m ? f : f + 1;
+        const float *src = p.alphas + ((size_t)slot * p.B + b) * H;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            v[it][j] = (f < len && lab[j] >= 0) ? src[lane + 64 * j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < FPW; ++it) {
+        const int f = f0 + 4 * it;
+        float t0 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool sh = lab[j] == l0;
+            t0 += sh ? v[it][j] : 0.f;
+            if (!sh && v[it][j] != 0.f) atomicAdd(&bins[lab[j]], v[it][j]);
+        }
+        const float tot = dpp_wave_sum(t0);
+        __syncthreads();
+        float *dst = p.grad + ((size_t)f * p.B + b) * C;
+        for (int c = lane; c < C; c += 64) {
+            const float x = bins[c] + (c == l0 ? tot : 0.f);
+            bins[c] = 0.f;
+            if (f < p.T) dst[c] = x;
+        }
+        __syncthreads();
+    }
 }
 
 struct FwdParams {
@@ -1458,7 +1540,8 @@ extern "C" int64_t asr_lattice_fwbw_workspace_bytes(int T, int B, int C, int N) 
     if (T < 0 || B < 0 || N < 0) return -1;
     // [T+2, B, round_up(N,64)] f32 (+1 slot: beta_len, +1: spare)
     const int64_t H = (N + 63) / 64 * 64;
-    return (int64_t)(T + 2) * B * H * (int64_t)sizeof(float) + (int64_t)B * 4 + 256;
+    // + [B] band-kernel flags + [B] split-scatter flags
+    return (int64_t)(T + 2) * B * H * (int64_t)sizeof(float) + (int64_t)B * 8 + 256;
 }
 
 extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
@@ -1492,6 +1575,8 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
     p.skip = nullptr;
+    p.split = nullptr;
+    bool split_scatter = false;
 
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
@@ -1507,7 +1592,15 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
         // check runs the generic body inside the same launch
         const int H = round_up(N, 64);
         const size_t lds_sl = (size_t)(4 * H + 6 * Cpad + 64 + 2 * H) * sizeof(float);
-        if (C <= H)
+        // Experimental (ASR_LATTICE_SPLIT_SCATTER=1): the per-class posterior sums leave
+        // the sequential chain (FL == 2 + lattice_scatter_kernel).  Correct (same tests)
+        // but slower today: 114 + 60 us vs 149 us fused on the B=512 mono numerator.
+        const char *split_env = getenv("ASR_LATTICE_SPLIT_SCATTER");
+        split_scatter = C <= H && T > 0 && split_env && split_env[0] == '1';
+        if (split_scatter) {
+            kern = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 2> : lattice_fwbw_sl_kernel<4, 8, 2>;
+            p.split = (int *)((char *)workspace + (size_t)(T + 2) * B * H * sizeof(float)) + B;
+        } else if (C <= H)
             kern = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 1> : lattice_fwbw_sl_kernel<4, 8, 1>;
         else
             kern = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 0> : lattice_fwbw_sl_kernel<4, 8, 0>;
@@ -1538,6 +1631,23 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
             return ASR_EUNSUPPORTED;
     }
     hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, s, p);
+    if (split_scatter) {
+        constexpr int FPW = 4;
+        const int nj = round_up(N, 64) / 64;
+        void (*sk)(FwbwParams);
+        switch (nj) {
+            case 1: sk = lattice_scatter_kernel<1, FPW>; break;
+            case 2: sk = lattice_scatter_kernel<2, FPW>; break;
+            case 3: sk = lattice_scatter_kernel<3, FPW>; break;
+            case 4: sk = lattice_scatter_kernel<4, FPW>; break;
+            case 5: sk = lattice_scatter_kernel<5, FPW>; break;
+            case 6: sk = lattice_scatter_kernel<6, FPW>; break;
+            case 7: sk = lattice_scatter_kernel<7, FPW>; break;
+            default: sk = lattice_scatter_kernel<8, FPW>; break;
+        }
+        hipLaunchKernelGGL(sk, dim3(B, (T + 4 * FPW - 1) / (4 * FPW)), dim3(256),
+                           (size_t)4 * Cpad * sizeof(float), s, p);
+    }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 

@@ -370,3 +370,20 @@ def test_band_kernel_matches_golden(monkeypatch):
         np.testing.assert_allclose(logZ, g['fwbw_logZ'], rtol=RTOL_LOSS)
         np.testing.assert_allclose(grad, g['fwbw_grad'], atol=grad_atol(logZ))
         assert np.abs(zb - logZ).max() < 1e-3
+
+
+def test_split_scatter_matches_golden_and_mixed_batch(monkeypatch, oracle_lib):
+    """ASR_LATTICE_SPLIT_SCATTER=1: the scan leaves the state posteriors in the workspace
+    and lattice_scatter_kernel sums them per class (csrc/lattice.hip, FL == 2); same
+    golden vectors and tolerances, and the mixed batch of
+    test_generic_graph_with_per_arc_labels (state-labelled and per-arc-labelled
+    utterances in one launch: their workspace regions must not overlap)."""
+    monkeypatch.setenv('ASR_LATTICE_SPLIT_SCATTER', '1')
+    for name in LATTICES:
+        g = golden(name + '.npz')
+        mats = [g['gm%d' % i] for i in range(8)]
+        logZ, grad, zb = run_fwbw(g['lp'], g['lens'], mats, want_bwd=True)
+        np.testing.assert_allclose(logZ, g['fwbw_logZ'], rtol=RTOL_LOSS)
+        np.testing.assert_allclose(grad, g['fwbw_grad'], atol=grad_atol(logZ))
+        assert np.abs(zb - logZ).max() < 1e-3
+    test_generic_graph_with_per_arc_labels(oracle_lib)
