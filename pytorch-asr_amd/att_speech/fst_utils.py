@@ -648,3 +648,190 @@ class CTCGraphGen(BaseGraphGen):
     def get_hc_fst(self):
         args = self.graph_build_args if self.context_order == 2 else {}
         return DecodingTransducer(self.num_symbols, self.context_order, **args)
+
+
+# ----------------------------------------------------------------------------
+# Hypothesis state sets on a language-model FST (reference fst_utils.py:23-188:
+# score_nodes, reduce_weights, expand_epsilon, expand_non_epsilon, expand,
+# expand_all).  A hypothesis of the LM-fused beam search is a bag
+# {LM state: cost} (cost = -log p); one decoder step pushes every bag through
+# the arcs of one input label and through the epsilon (back-off) arcs behind
+# them.  The reference walks Python dicts arc by arc, one beam and one label at
+# a time; here the LM is a CSR array bundle (att_speech/lm_fst.py) and ALL beams
+# and ALL labels of a step are expanded together: arcs gathered with one index
+# expression, equal (beam, label, state) targets merged with a sort + segmented
+# logaddexp / min, the epsilon closure done level by level in the topological
+# rank of the LM's epsilon graph (so every state's cost is final when it is
+# pushed on).  The dict functions of the reference keep their names and
+# semantics on top of that core.
+# ----------------------------------------------------------------------------
+def reduce_weights(ws, use_log_probs):
+    """-log(sum exp(-w)) if use_log_probs else min(w); inf for an empty list (:46-58)."""
+    ws = np.asarray(list(ws), np.float64)
+    if ws.size == 0:
+        return float('inf')
+    if use_log_probs:
+        return float(-np.logaddexp.reduce(-ws))
+    return float(ws.min())
+
+
+def _reduce_by_key(key, cost, use_log_probs):
+    if key.size == 0:
+        return key, cost
+    order = np.argsort(key, kind='stable')
+    k, c = key[order], cost[order]
+    idx = np.nonzero(np.r_[True, k[1:] != k[:-1]])[0]
+    if use_log_probs:
+        with np.errstate(invalid='ignore'):
+            red = -np.logaddexp.reduceat(-c, idx)
+    else:
+        red = np.minimum.reduceat(c, idx)
+    return k[idx], red
+
+
+def _gather_arcs(lo, hi):
+    cnt = hi - lo
+    total = int(cnt.sum())
+    owner = np.repeat(np.arange(len(lo)), cnt)
+    offs = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    return owner, np.repeat(lo, cnt) + offs
+
+
+def _expand_epsilon_dfs(LG, nodes, use_log_probs):
+    """Reference algorithm (:86-137) for LMs whose epsilon graph has a cycle
+    somewhere: depth-first topological order over the part reachable from
+    `nodes`; a cycle reachable from them is an error."""
+    preds, done, order = {}, set(), []
+    for s0 in nodes:
+        preds.setdefault(s0, []).append((-1, nodes[s0]))
+        if s0 in done:
+            continue
+        stack = [(s0, iter(range(int(LG.ptr[s0]), int(LG.ptr_ne[s0]))))]
+        on_stack = {s0}
+        while stack:
+            s, it = stack[-1]
+            for a in it:
+                n = int(LG.dst[a])
+                preds.setdefault(n, []).append((s, float(LG.weight[a])))
+                if n in done:
+                    continue
+                if n in on_stack:
+                    raise ValueError("LG has epsilon-cycles!")
+                on_stack.add(n)
+                stack.append((n, iter(range(int(LG.ptr[n]), int(LG.ptr_ne[n])))))
+                break
+            else:
+                stack.pop()
+                on_stack.discard(s)
+                done.add(s)
+                order.append(s)
+    out = {-1: 0.0}
+    for s in order[::-1]:
+        out[s] = reduce_weights([out[p] + w for p, w in preds[s]], use_log_probs)
+    del out[-1]
+    return out
+
+
+def _epsilon_closure(LG, grp, st, w, use_log_probs):
+    """grp/st/w: parallel arrays, (grp, st) unique.  Returns them closed under the
+    epsilon arcs, sorted by (grp, st)."""
+    S = LG.num_states()
+    key, w = _reduce_by_key(grp * S + st, w, use_log_probs)
+    if key.size == 0:
+        return grp[:0], st[:0], w
+    rank = LG.eps_rank()
+    if rank is None:
+        g_all, s_all, w_all = [], [], []
+        grp, st = key // S, key % S
+        for g in np.unique(grp):
+            m = grp == g
+            d = _expand_epsilon_dfs(LG, dict(zip(st[m].tolist(), w[m].tolist())),
+                                    use_log_probs)
+            g_all.append(np.full(len(d), g, np.int64))
+            s_all.append(np.fromiter(d.keys(), np.int64, len(d)))
+            w_all.append(np.fromiter(d.values(), np.float64, len(d)))
+        key, w = _reduce_by_key(np.concatenate(g_all) * S + np.concatenate(s_all),
+                                np.concatenate(w_all), use_log_probs)
+        return key // S, key % S, w
+    level, top = 0, int(rank.max())
+    while level <= top:
+        st = key % S
+        sel = np.nonzero((rank[st] == level) & (LG.ptr_ne[st] > LG.ptr[:-1][st]))[0]
+        if sel.size:
+            owner, arcs = _gather_arcs(LG.ptr[:-1][st[sel]], LG.ptr_ne[st[sel]])
+            nk = (key[sel] // S)[owner] * S + LG.dst[arcs]
+            key, w = _reduce_by_key(np.concatenate([key, nk]),
+                                    np.concatenate([w, w[sel][owner] + LG.weight[arcs]]),
+                                    use_log_probs)
+        level += 1
+    return key // S, key % S, w
+
+
+def expand_all_batched(LG, num_classes, grp, st, w, use_log_probs=False):
+    """Push the bags `grp` (any non-negative ids, e.g. beam indices) through the arcs
+    of EVERY input label at once.  Returns (bag, state, cost) arrays sorted by bag
+    with bag = grp * num_classes + ilabel.  Like the reference's expand_all
+    (:163-185) the arcs of label 0 form bag `grp * num_classes + 0`, and a label
+    >= num_classes is an IndexError."""
+    grp = np.asarray(grp, np.int64); st = np.asarray(st, np.int64)
+    w = np.asarray(w, np.float64)
+    owner, arcs = _gather_arcs(LG.ptr[:-1][st], LG.ptr[1:][st])
+    il = LG.ilabel[arcs]
+    if il.size and int(il.max()) >= num_classes:
+        raise IndexError("LM input label %d outside the %d classes" % (il.max(), num_classes))
+    bag = grp[owner] * num_classes + il
+    return _epsilon_closure(LG, bag, LG.dst[arcs], w[owner] + LG.weight[arcs], use_log_probs)
+
+
+def _bag_arrays(nodes):
+    n = len(nodes)
+    return (np.fromiter(nodes.keys(), np.int64, n), np.fromiter(nodes.values(), np.float64, n))
+
+
+def expand_epsilon(LG, nodes, use_log_probs):
+    """All states reachable from the bag over epsilon arcs, costs summed over the
+    epsilon paths (:86-137)."""
+    st, w = _bag_arrays(nodes)
+    _, st, w = _epsilon_closure(LG, np.zeros(len(st), np.int64), st, w, use_log_probs)
+    return dict(zip(st.tolist(), w.tolist()))
+
+
+def expand_non_epsilon(LG, nodes, label, use_log_probs=False):
+    """(:140-154)"""
+    st, w = _bag_arrays(nodes)
+    owner, arcs = _gather_arcs(LG.ptr[:-1][st], LG.ptr[1:][st])
+    m = LG.ilabel[arcs] == label
+    k, c = _reduce_by_key(LG.dst[arcs][m], (w[owner] + LG.weight[arcs])[m], use_log_probs)
+    return dict(zip(k.tolist(), c.tolist()))
+
+
+def expand(LG, nodes, label, use_log_probs=False):
+    """(:157-161)"""
+    return expand_epsilon(LG, expand_non_epsilon(LG, nodes, label, use_log_probs),
+                          use_log_probs)
+
+
+def expand_all(LG, num_classes, nodes, use_log_probs=False):
+    """One bag per input label (:163-185)."""
+    st, w = _bag_arrays(nodes)
+    bag, st, w = expand_all_batched(LG, num_classes, np.zeros(len(st), np.int64), st, w,
+                                    use_log_probs)
+    out = [{} for _ in range(num_classes)]
+    for b, s, c in zip(bag.tolist(), st.tolist(), w.tolist()):
+        out[b][s] = c
+    return out
+
+
+def score_nodes(LG, nodes, final=False, use_log_probs=False, expand_symbol=None):
+    """Cost of all paths ending in the bag; final: optionally extend by
+    `expand_symbol`, then count paths into final states only (:23-43)."""
+    if final:
+        if expand_symbol is not None:
+            after = expand(LG, nodes, LG.input_symbols().find(expand_symbol))
+            assert not set(after).intersection(set(nodes))
+            after.update(nodes)
+            nodes = after
+        ws = [LG.final(k) + v for k, v in nodes.items()]
+    else:
+        ws = list(nodes.values())
+    return reduce_weights(ws, use_log_probs)

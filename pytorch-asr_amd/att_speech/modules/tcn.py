@@ -1,9 +1,9 @@
 """att_speech.modules.tcn — TCN language-model + local-attention decoder of the
 reference (att_speech/modules/tcn.py): Chomp1d (:33-43), TemporalBlock (:46-86),
 TCN (:89-116), LocalAttention (:119-230), AttentionDecoderTCN (:233-585) with
-its training `forward` (:357-440) and step-wise beam `decode` (:442-585, plain
-BeamSearch — the LM-fused searches need an external LM FST and are out of
-scope).  Same constructor kwargs, return dicts and state_dict keys
+its training `forward` (:357-440) and step-wise beam `decode` (:442-585: plain
+BeamSearch, or with `lm_file` the LM-fused BeamSearchLM / RescoreSearchLM /
+GraphSearch over an att_speech.lm_fst.LmFst).  Same constructor kwargs, return dicts and state_dict keys
 (`tcn.network.{i}.net.conv{j}.{bias,weight_g,weight_v}`, ...).
 
 This stage is dense small-GEMM / elementwise work on [B*beam, 384] states; it
@@ -16,7 +16,9 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from att_speech.modules.beam_search import BeamSearch
+from att_speech.lm_fst import LmFst
+from att_speech.modules.beam_search import (BeamSearch, BeamSearchLM, GraphSearch,
+                                             RescoreSearchLM)
 from att_speech.utils import get_mask
 
 
@@ -169,9 +171,12 @@ class AttentionDecoderTCN(nn.Module):
                  use_graph_search=False, graph_search_history_len=-1,
                  graph_search_merge_threshold=0.8, **kwargs):
         super(AttentionDecoderTCN, self).__init__(**kwargs)
-        if lm_file or use_graph_search:
-            raise NotImplementedError(
-                "LM-fused / graph search needs an external LM FST (out of scope)")
+        self.rescore = None
+        self.use_graph_search = use_graph_search
+        self.min_attention_pos = min_attention_pos
+        self.keep_eos_score = keep_eos_score
+        self.graph_search_history_len = graph_search_history_len
+        self.graph_search_merge_threshold = graph_search_merge_threshold
         self.coverage_tau = coverage_tau
         self.coverage_weight = coverage_weight
         self.encoded_size = sample_batch["features"].size()[2]
@@ -201,7 +206,36 @@ class AttentionDecoderTCN(nn.Module):
         self.TRANSCRIPTION_LEN_GUARD = 250
         self.lm_weight = lm_weight
         self.label_smoothing = label_smoothing
-        self.lm = None
+        if lm_file:
+            # (:293-300) the reference reads a pywrapfst.Fst; arcs of an LmFst are
+            # always input-label sorted
+            self.lm = lm_file if isinstance(lm_file, LmFst) else LmFst.read(lm_file)
+            assert self.vocabulary is not None
+        else:
+            self.lm = None
+        self.alphabet_mapping = self.create_alphabet_mapping()
+
+    def create_alphabet_mapping(self):
+        """model class id -> LM input label (:306-327); symbols the LM does not know
+        (and EOS) map to its <spc>."""
+        if self.lm is None:
+            return None
+        lm_ids, lm_syms = zip(*list(self.lm.input_symbols()))
+        default_id = lm_ids[lm_syms.index('<spc>')]
+        mapping = []
+        for s in list(self.vocabulary) + ['<eos>']:
+            if s == ' ':
+                s = '<spc>'
+            mapping.append(lm_ids[lm_syms.index(s)] if s in lm_syms else default_id)
+        return mapping
+
+    def hash_dec(self, decoded):
+        """hash of the last `history` letters of a hypothesis (:335-345)"""
+        hs = (self.graph_search_history_len if self.graph_search_history_len >= 0
+              else self.tcn.eff_history)
+        if hs == 0:
+            return 0
+        return hash(tuple([-1] * (hs - len(decoded)) + decoded[-hs:].tolist()))
 
     def forward(self, encoded, encoded_lens, texts, text_lens,
                 return_att_weights=False, **kwargs):
@@ -278,8 +312,21 @@ class AttentionDecoderTCN(nn.Module):
                return_attention=False, print_debug=False, **kwargs):
         """(:476-585) beam search, at most TRANSCRIPTION_LEN_GUARD steps."""
         batch_size, beam_size = encoded.size(1), self.beam_size
-        beam_search = BeamSearch(batch_size, beam_size, encoded.device,
-                                 self.num_classes, self.length_normalization)
+        base_args = (batch_size, beam_size, encoded.device, self.num_classes,
+                     self.length_normalization)
+        if self.lm:
+            lm_args = (self.lm, self.lm_weight, self.alphabet_mapping, self.min_attention_pos,
+                       self.coverage_tau, self.coverage_weight) + base_args
+            if self.rescore:
+                beam_search = RescoreSearchLM(self.rescore, *lm_args,
+                                              keep_eos_score=self.keep_eos_score)
+            elif self.use_graph_search:
+                beam_search = GraphSearch(self.hash_dec, self.graph_search_merge_threshold,
+                                          *lm_args, keep_eos_score=self.keep_eos_score)
+            else:
+                beam_search = BeamSearchLM(*lm_args, keep_eos_score=self.keep_eos_score)
+        else:
+            beam_search = BeamSearch(*base_args)
         beam_search.print_debug = print_debug
         enc_state = self.enc_initial_state(encoded, encoded_lens, beam_size, batch_size)
         all_att_weights, all_logits = [], []

@@ -327,6 +327,130 @@ def golden_tcn_beam():
     save('tcn_beam.npz', **out)
 
 
+def _toy_lm(lm_mod, rng):
+    """6-state LM over <spc>, a, b, c (labels 1..4) with two levels of epsilon back-off:
+    4,5 -> 1|2 -> 0; state 0 has every label, the others only some."""
+    src, dst, il, w = [], [], [], []
+    for s in range(6):
+        labs = [1, 2, 3, 4] if s == 0 else sorted(rng.choice([1, 2, 3, 4], size=2, replace=False))
+        for l in labs:
+            for _ in range(1 + (s % 2)):                 # odd states: two arcs per label
+                src.append(s); dst.append(int(rng.integers(0, 6))); il.append(int(l))
+                w.append(float(rng.uniform(0.2, 2.5)))
+    for s, d in [(1, 0), (2, 0), (3, 0), (4, 1), (4, 2), (5, 2)]:
+        src.append(s); dst.append(d); il.append(0); w.append(float(rng.uniform(0.3, 1.2)))
+    final = np.array([0.4, 1.0, np.inf, 0.7, np.inf, 0.2])
+    syms = lm_mod.SymbolTable([(0, '<eps>'), (1, '<spc>'), (2, 'a'), (3, 'b'), (4, 'c')])
+    return (lm_mod.LmFst(6, 0, src, dst, il, il, w, final, syms, syms),
+            dict(lm_src=np.array(src), lm_dst=np.array(dst), lm_il=np.array(il),
+                 lm_w=np.array(w), lm_final=final))
+
+
+def golden_beam_lm():
+    """BeamSearchLM / RescoreSearchLM / GraphSearch (reference beam_search.py:185-648) and
+    the LM bag functions (reference fst_utils.py:23-188) on a toy LM and seeded step
+    inputs.  The reference classes are Python 2: they are executed here from the file's
+    text through a minimal 2-to-3 shim applied in memory (xrange -> range, .iteritems()
+    -> .items(), the two `print "..."` debug statements -> pass, dict.values() handed to
+    reduce_weights as a list); nothing of it is written to disk.  The LM object is the
+    build's att_speech/lm_fst.py LmFst (loaded by path; same start()/arcs()/final()
+    surface as pywrapfst's)."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location(
+        'amd_lm_fst', os.path.join(ROOT, 'pytorch-asr_amd/att_speech/lm_fst.py'))
+    lm_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lm_mod)
+
+    ref_fst.xrange = range
+    orig_reduce = ref_fst.reduce_weights
+    ref_fst.reduce_weights = lambda ws, u: orig_reduce(list(ws), u)
+    text = open(os.path.join(REF, 'att_speech/modules/beam_search.py')).read()
+    text = re.sub(r'print "[^"]*" % \((?:[^()]|\([^()]*\)|\((?:[^()]|\([^()]*\))*\))*\)',
+                  'pass', text)
+    text = text.replace('xrange', 'range').replace('.iteritems()', '.items()')
+    ns = {}
+    exec(compile(text, 'beam_search.py[2to3 shim]', 'exec'), ns)
+
+    rng = np.random.default_rng(77)
+    lm, out = _toy_lm(lm_mod, rng)
+    # bag functions
+    nodes = {0: 0.0, 3: 0.4, 5: 1.1}
+    for name, logp in (('log', True), ('min', False)):
+        allb = ref_fst.expand_all(lm, 7, dict(nodes), logp)
+        flat = [(l, k, v) for l, d in enumerate(allb) for k, v in sorted(d.items())]
+        out['bags_%s' % name] = np.array(flat, np.float64)
+        e = ref_fst.expand_epsilon(lm, {4: 0.1, 5: 0.2, 1: 0.3}, logp)
+        out['eps_%s' % name] = np.array(sorted(e.items()), np.float64)
+        # a bag whose <spc>-successors are disjoint from it (asserted by score_nodes)
+        spc_bag = next({a: 0.5, b: 0.1} for a in range(6) for b in range(a + 1, 6)
+                       if not set(ref_fst.expand(lm, {a: 0., b: 0.}, 1)) & {a, b})
+        out['spc_bag'] = np.array(sorted(spc_bag.items()), np.float64)
+        out['score_%s' % name] = np.array([
+            ref_fst.score_nodes(lm, dict(nodes), False, logp),
+            ref_fst.score_nodes(lm, dict(nodes), True, logp),
+            ref_fst.score_nodes(lm, dict(spc_bag), True, logp, '<spc>')])
+
+    C, beam, T, steps = 7, 4, 12, 11
+    mapping = [1, 1, 1, 2, 3, 4, 1]
+    logits = rng.standard_normal((steps, 1, beam, C)).astype(np.float32) * 1.5
+    logits[4:, :, :, -1] += 2.5
+    att = rng.standard_normal((steps, T, beam)).astype(np.float32)
+    for i in range(steps):
+        att[i, min(T - 1, 2 + i)] += 3.0
+    att = torch.softmax(t(att), 1).numpy()
+    out.update(logits=logits, att=att, mapping=np.array(mapping))
+
+    def drive(bs, tag, n=steps, nb=beam):
+        letters, maps, scores = [], [], []
+        for i in range(n):
+            l, m = bs.step(t(logits[i][:, :nb]).clone(), att_weights=t(att[i][:, :nb]).clone())
+            letters.append(l.numpy().copy()); maps.append(m.numpy().copy())
+            scores.append(bs.scores.numpy().copy())
+        out[tag + '_letters'] = np.stack(letters)
+        out[tag + '_maps'] = np.stack(maps)
+        out[tag + '_scores'] = np.stack(scores)
+        out[tag + '_nfinished'] = np.array(len(bs.finished))
+        out[tag + '_finished_scores'] = np.array([float(f[0]) for f in bs.finished])
+        out[tag + '_finished_beams'] = np.array([int(f[2]) for f in bs.finished])
+        fl = [np.asarray(f[1]) for f in bs.finished]
+        out[tag + '_finished_flat'] = np.concatenate(fl) if fl else np.zeros(0, np.int64)
+        out[tag + '_finished_lens'] = np.array([len(f) for f in fl], np.int64)
+        out[tag + '_best'] = np.asarray(bs.best_finished[0], np.int64)
+        out[tag + '_best_score'] = np.array(float(bs.best_finished_scores[0]))
+        for k, v in bs.best_finished_scores_elements.items():
+            out[tag + '_el_' + k] = np.array(v, np.float64)
+        out[tag + '_estimations'] = bs.estimations.numpy()
+        st = [(b, k, v) for b, d in enumerate(bs.fst_states) for k, v in sorted(d.items())]
+        out[tag + '_fst_states'] = np.array(st, np.float64).reshape(-1, 3)
+        if bs.coverage is not None:
+            out[tag + '_coverage'] = bs.coverage.numpy()
+        return bs
+
+    dev = torch.device('cpu')
+    drive(ns['BeamSearchLM'](lm, 0.5, mapping, 0.3, 0.1, 0.2, 1, beam, dev, C, 0.6,
+                             keep_eos_score=False), 'lm')
+    drive(ns['BeamSearchLM'](lm, 0.8, mapping, 0.2, 0.1, 0.0, 1, beam, dev, C, 0.0,
+                             keep_eos_score=True), 'lmk')
+    sentence = [3, 4, 5, 2, 3]
+    out['sentence'] = np.array(sentence)
+    r = drive(ns['RescoreSearchLM'](sentence, lm, 0.5, mapping, 0.3, 0.1, 0.2, 1, 1, dev, C,
+                                    0.6, keep_eos_score=False), 'rs', n=6, nb=1)
+    out['rs_attentions'] = r.attentions.numpy()
+
+    def hash_dec(decoded, hs=2):
+        return hash(tuple([-1] * (hs - len(decoded)) + decoded[-hs:].tolist()))
+    g = drive(ns['GraphSearch'](hash_dec, 0.3, lm, 0.5, mapping, 0.3, 0.1, 0.2, 1, beam, dev,
+                                C, 0.6, keep_eos_score=False), 'gs')
+    G = g.get_graph()[0]
+    out['gs_V'] = np.array([[v[0], -1 if v[1] == '<sos>' else v[1], int(bool(v[4]))]
+                            for v in G['V']], np.int64)
+    out['gs_V_scores'] = np.array([v[2] for v in G['V']], np.float64)
+    out['gs_E'] = np.array([[e[0], e[1], int(e[2] == 'merged')] for e in G['E']],
+                           np.int64).reshape(-1, 3)
+    save('beam_lm.npz', **out)
+
+
 if __name__ == '__main__':
     golden_lattice_mono()
     golden_lattice_bigram()
@@ -335,3 +459,4 @@ if __name__ == '__main__':
     golden_normalized_acts()
     golden_embedders_and_greedy()
     golden_tcn_beam()
+    golden_beam_lm()
