@@ -449,6 +449,7 @@ struct LstmTeamCtl {
     unsigned *err;          // timeout word
     unsigned spin_limit;
     int bt0, nbt;           // first batch tile of this launch, batch tiles in total
+    int xcd_teams;          // 0: grid (jt, batch tile, dir); else teams of the XCD-affine 1-D grid
     size_t rows;            // rows of one hbuf / dgbuf plane (>= 32 * nbt)
 };
 
@@ -465,7 +466,18 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     __bf16 *h_lds = reinterpret_cast<__bf16 *>(smem + KS * 1024 + ASR_GLDS_BYTES);   // 4 KiB
     __shared__ int dead_s;
     const int H = p.H, B = p.B, T = p.T;
-    const int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
+    int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
+    if (ctl.xcd_teams) {
+        // 1-D grid, team = blockIdx.x % 8 + 8 * (slot / njt): the H/64 workgroups that
+        // exchange h_t / dgates_t every step have equal blockIdx % 8, i.e. sit on one XCD
+        // under the observed round-robin placement (speed only — the hand-off protocol
+        // does not depend on it); surplus workgroups of the padded grid leave at once
+        const int slot = blockIdx.x >> 3, team = (slot / (p.H / 64)) * 8 + (blockIdx.x & 7);
+        if (team >= ctl.xcd_teams) return;
+        jt = slot % (p.H / 64);
+        btile = (team >> 1) + ctl.bt0;
+        dir = team & 1;
+    }
     const int j0 = jt * 64, b0 = btile * (8 * NE), njt = H / 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int gate = wave >> 1, js = wave & 1;
@@ -643,7 +655,18 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
     __bf16 *dg_lds = reinterpret_cast<__bf16 *>(smem + KS4 * 1024 + ASR_GLDS_BYTES);   // 16 KiB
     __shared__ int dead_s;
     const int H = p.H, B = p.B, T = p.T, H4 = 4 * p.H;
-    const int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
+    int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
+    if (ctl.xcd_teams) {
+        // 1-D grid, team = blockIdx.x % 8 + 8 * (slot / njt): the H/64 workgroups that
+        // exchange h_t / dgates_t every step have equal blockIdx % 8, i.e. sit on one XCD
+        // under the observed round-robin placement (speed only — the hand-off protocol
+        // does not depend on it); surplus workgroups of the padded grid leave at once
+        const int slot = blockIdx.x >> 3, team = (slot / (p.H / 64)) * 8 + (blockIdx.x & 7);
+        if (team >= ctl.xcd_teams) return;
+        jt = slot % (p.H / 64);
+        btile = (team >> 1) + ctl.bt0;
+        dir = team & 1;
+    }
     const int j0 = jt * 64, b0 = btile * (8 * NE), njt = H / 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kq = wave >> 1, js = wave & 1;
@@ -884,7 +907,17 @@ bool launch_persist(void (*const kerns[3])(P, LstmTeamCtl), const P &p, int B, i
     for (int bt0 = 0; bt0 < nbt; bt0 += max_bt) {
         ctl.bt0 = bt0;
         const int n = nbt - bt0 < max_bt ? nbt - bt0 : max_bt;
-        hipLaunchKernelGGL(kern, dim3(njt, n, 2), dim3(512), lds, s, p, ctl);
+        // XCD-affine placement of the teams when the grid padded to a multiple of 8 teams
+        // still is one workgroup per CU (ASR_LSTM_XCD=0: plain 3-D grid)
+        const int padded = 8 * njt * ((2 * n + 7) / 8);
+        static const bool xcd_on = !(getenv("ASR_LSTM_XCD") && getenv("ASR_LSTM_XCD")[0] == '0');
+        if (xcd_on && padded <= cus) {
+            ctl.xcd_teams = 2 * n;
+            hipLaunchKernelGGL(kern, dim3(padded), dim3(512), lds, s, p, ctl);
+        } else {
+            ctl.xcd_teams = 0;
+            hipLaunchKernelGGL(kern, dim3(njt, n, 2), dim3(512), lds, s, p, ctl);
+        }
     }
     return true;
 }
