@@ -28,10 +28,11 @@ for _ in range(3):
     y, ybf, gates, cs = _native.lstm_bidir_fwd(gx, whh, lens)
     dg = _native.lstm_bidir_bwd(dy, whhT, lens, gates, cs)
 torch.cuda.synchronize()
-v = y[0].reshape(B, 2, H)[0::32].reshape(-1, 2, H // 64, 64)[..., :6].reshape(-1, 6)
+R = int(os.environ.get('TILE_ROWS', '24'))    # batch rows per tile the host picked (24 at B=512)
+v = y[0].reshape(B, 2, H)[0::R].reshape(-1, 2, H // 64, 64)[..., :6].reshape(-1, 6)
 m = v.mean(0).tolist()
 print('fwd B=%d T=%d cycles/step: %s  total %.0f' % (B, T, ' '.join('%.0f' % x for x in m), sum(m)))
 print('     max over workgroups: %s' % ' '.join('%.0f' % x for x in v.max(0)[0].tolist()))
-w = dg[0].reshape(B, 2, 4 * H)[0::32][..., :H].reshape(-1, 2, H // 64, 64)[..., :6].reshape(-1, 6).float() * 16
+w = dg[0].reshape(B, 2, 4 * H)[0::R][..., :H].reshape(-1, 2, H // 64, 64)[..., :6].reshape(-1, 6).float() * 16
 m = w.mean(0).tolist()
 print('bwd B=%d T=%d cycles/step: %s  total %.0f' % (B, T, ' '.join('%.0f' % x for x in m), sum(m)))
