@@ -501,7 +501,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     float c[NE];
     __bf16 hq[NE];
     int len[NE];
-    size_t gxrow[NE];            // offset of (b, dir, gate 0, j) inside one frame of gx
+    // Every per-step global access of the pointwise part goes through a raw buffer with a
+    // per-element 32-bit byte offset computed ONCE here plus a wave-uniform frame offset in
+    // an SGPR: no 64-bit address arithmetic in the step loop, and masked rows simply carry
+    // an out-of-range offset (stores dropped).  The host checks every tensor is < 4 GiB.
+    typedef unsigned int u32;
+    constexpr u32 OOBV = 0xFFFFFFFFu;
+    constexpr u32 GXE = GXB ? 2u : 4u;
+    u32 vgx[NE], vy[NE], vyb[NE], vcs[NE], vg[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int b = b0 + e * 8 + wave;
@@ -509,9 +516,27 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         c[e] = 0.f;
         hq[e] = (__bf16)0.f;
         len[e] = b < B ? p.lens[b] : 0;
-        gxrow[e] = ((size_t)bc * 2 + dir) * 4 * H + j;
+        vgx[e] = (u32)((bc * 2 + dir) * 4 * H + j) * GXE;
+        vy[e] = b < B ? (u32)((b * 2 + dir) * H + j) * 4u : OOBV;
+        vyb[e] = b < B ? (u32)(((size_t)(dir * (T + 2) + 1) * B + b) * H + j) * 2u : OOBV;
+        vcs[e] = b < B ? (u32)((dir * B + b) * H + j) * 4u : OOBV;
+        vg[e] = b < B ? (u32)((dir * B + b) * 4 * H + j) * 4u : OOBV;
     }
-    const size_t gxframe = (size_t)B * 2 * 4 * H;
+    const u32 fgx = (u32)B * 8u * H * GXE, fy = (u32)B * 2u * H * 4u, fyb = (u32)B * H * 2u;
+    const u32 fcs = (u32)B * 2u * H * 4u, fg = (u32)B * 8u * H * 4u, H4b = (u32)H * 4u;
+    const __amdgpu_buffer_rsrc_t gxR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(p.gx), 0, (int)((u32)T * fgx), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yR = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((u32)T * fy), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ybR = __builtin_amdgcn_make_buffer_rsrc(
+        p.ybf, 0, (int)((u32)(2 * (T + 2)) * fyb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t csR = __builtin_amdgcn_make_buffer_rsrc(p.csave, 0, (int)((u32)T * fcs), 0x00020000);
+    const __amdgpu_buffer_rsrc_t gR = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((u32)T * fg), 0x00020000);
+    auto ld_gx = [&](u32 voff, u32 soff) -> float {
+        if constexpr (GXB)
+            return (float)__builtin_bit_cast(__bf16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(gxR, voff, soff, 0));
+        else
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gxR, voff, soff, 0));
+    };
 
     // Software pipeline: the x·W_ih terms of step s+1 are fetched during step s
     // (behind the hand-off tile in the wave's in-order vmcnt queue, never in
@@ -523,25 +548,24 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
 #pragma unroll
         for (int e = 0; e < NE; ++e)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pgx[e][g] = load_gx<GXB>(p.gx, (size_t)t0 * gxframe + gxrow[e] + (size_t)g * H);
+            for (int g = 0; g < 4; ++g) pgx[e][g] = ld_gx(vgx[e], (u32)t0 * fgx + (u32)g * H * GXE);
     }
     float sog[NE][4], soh[NE], sc[NE];
     bool sact[NE];
     int st = 0;
     auto bulk_store = [&]() {
+        const u32 ust = (u32)st;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const int b = b0 + e * 8 + wave;
-            if (b < B) {
-                p.y[(((size_t)st * B + b) * 2 + dir) * H + j] = soh[e];
-                p.ybf[(((size_t)dir * (T + 2) + st + 1) * B + b) * H + j] = (__bf16)soh[e];
-                p.csave[(((size_t)st * 2 + dir) * B + b) * H + j] = sc[e];
-                if (sact[e]) {
-                    const size_t gsave = ((((size_t)st * 2 + dir) * B + b) * 4) * H + j;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, soh[e]), yR, vy[e], ust * fy, 0);
+            __builtin_amdgcn_raw_buffer_store_b16(
+                (short)__builtin_bit_cast(unsigned short, (__bf16)soh[e]), ybR, vyb[e], ust * fyb, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sc[e]), csR, vcs[e], ust * fcs, 0);
+            const u32 vge = sact[e] ? vg[e] : OOBV;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) p.gates[gsave + (size_t)g * H] = sog[e][g];
-                }
-            }
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sog[e][g]), gR, vge,
+                                                      ust * fg + (u32)g * H4b, 0);
         }
     };
 
@@ -581,7 +605,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
             for (int e = 0; e < NE; ++e)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    ngx[e][g] = load_gx<GXB>(p.gx, (size_t)tn * gxframe + gxrow[e] + (size_t)g * H);
+                    ngx[e][g] = ld_gx(vgx[e], (u32)tn * fgx + (u32)g * H * GXE);
         }
         {
             f32x16 acc;
@@ -975,7 +999,10 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
                pk[2] = lstm_fwd_persist_kernel<KSV, 4, 0>; } }
         ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32)   // 48: W_hh slice spills
 #undef ASR_PICK
-        if (pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + ASR_GLDS_BYTES + 4096,
+        // the persistent kernel addresses gx / y / gates / ... with 32-bit byte offsets
+        const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (1ull << 32) &&
+                            (uint64_t)2 * (T + 2) * B * H * 2 < (1ull << 32);
+        if (fits32 && pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + ASR_GLDS_BYTES + 4096,
                                  ctl_words, s))
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
