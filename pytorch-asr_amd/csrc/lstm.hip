@@ -723,18 +723,42 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
     // operands of the cell backward at frame t: saved gates, dy, and the cell
     // state the step started from (c of the neighbouring frame, raw); c_t itself
     // is the neighbour value fetched one step earlier
+    // raw buffers, per-element 32-bit byte offsets computed once, frame offsets in SGPRs
+    // (as in the forward kernel; the host checks every tensor is < 4 GiB)
+    typedef unsigned int u32;
+    constexpr u32 OOBV = 0xFFFFFFFFu;
+    u32 vg[NE], vcs[NE], vdy[NE], vdg[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int b = b0 + e * 8 + wave;
+        vg[e] = (u32)((dir * B + bcl[e]) * 4 * H + j) * 4u;
+        vcs[e] = (u32)((dir * B + bcl[e]) * H + j) * 4u;
+        vdy[e] = (u32)(p.dy_shared ? bcl[e] * H + j : (bcl[e] * 2 + dir) * H + j) * 4u;
+        vdg[e] = b < B ? (u32)((b * 2 + dir) * H4 + j) * 2u : OOBV;
+    }
+    const u32 fg = (u32)B * 8u * H * 4u, fcs = (u32)B * 2u * H * 4u;
+    const u32 fdy = (u32)B * H * 4u * (p.dy_shared ? 1u : 2u), fdg = (u32)B * 2u * H4 * 2u;
+    const __amdgpu_buffer_rsrc_t gR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.gates), 0, (int)((u32)T * fg), 0x00020000);
+    const __amdgpu_buffer_rsrc_t csR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.csave), 0, (int)((u32)T * fcs), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dyR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.dy), 0, (int)((u32)T * fdy), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dgR = __builtin_amdgcn_make_buffer_rsrc(
+        p.dgates, 0, (int)((u32)T * fdg), 0x00020000);
+    auto ldf = [&](__amdgpu_buffer_rsrc_t R, u32 voff, u32 soff) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R, voff, soff, 0));
+    };
     struct Pre { float g[NE][4], cp[NE], dy[NE]; };
     auto fetch = [&](int t, Pre &q) {
         const int tp = dir == 0 ? t - 1 : t + 1;
         const int tpc = tp < 0 ? 0 : (tp >= T ? T - 1 : tp);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const size_t gsave = ((((size_t)t * 2 + dir) * B + bcl[e]) * 4) * H + j;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) q.g[e][g] = p.gates[gsave + (size_t)g * H];
-            q.cp[e] = p.csave[(((size_t)tpc * 2 + dir) * B + bcl[e]) * H + j];
-            q.dy[e] = p.dy[p.dy_shared ? ((size_t)t * B + bcl[e]) * H + j
-                                       : (((size_t)t * B + bcl[e]) * 2 + dir) * H + j];
+            for (int g = 0; g < 4; ++g) q.g[e][g] = ldf(gR, vg[e], (u32)t * fg + (u32)g * H * 4u);
+            q.cp[e] = ldf(csR, vcs[e], (u32)tpc * fcs);
+            q.dy[e] = ldf(dyR, vdy[e], (u32)t * fdy);
         }
     };
     Pre cur;
@@ -743,20 +767,18 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
         const int t0 = dir == 0 ? T - 1 : 0;
         fetch(t0, cur);
 #pragma unroll
-        for (int e = 0; e < NE; ++e) pcs[e] = p.csave[(((size_t)t0 * 2 + dir) * B + bcl[e]) * H + j];
+        for (int e = 0; e < NE; ++e) pcs[e] = ldf(csR, vcs[e], (u32)t0 * fcs);
     }
     __bf16 sod[NE][4];
     int st = 0;
     auto bulk_store = [&]() {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int b = b0 + e * 8 + wave;
-            if (b < B) {
-                __bf16 *dgo = p.dgates + (((size_t)st * B + b) * 2 + dir) * H4 + j;
+        for (int e = 0; e < NE; ++e)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) dgo[(size_t)g * H] = sod[e][g];
-            }
-        }
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_raw_buffer_store_b16(
+                    (short)__builtin_bit_cast(unsigned short, sod[e][g]), dgR, vdg[e],
+                    (u32)st * fdg + (u32)g * H * 2u, 0);
     };
 
     PSTAMP_DECL;
@@ -1058,7 +1080,8 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const voi
         pk[1] = lstm_bwd_persist_kernel<KSV, 3>; pk[2] = lstm_bwd_persist_kernel<KSV, 4>; }
         ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24)
 #undef ASR_PICK
-        if (pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 4) * 1024 + ASR_GLDS_BYTES + 16384,
+        const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (1ull << 32);   // 32-bit byte offsets
+        if (fits32 && pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 4) * 1024 + ASR_GLDS_BYTES + 16384,
                                  ctl_words, s))
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
