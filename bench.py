@@ -303,7 +303,7 @@ def main():
                                       '' if a.no_hooks else 'GradientClipping+PolyakDecay+', T),
                        'batch_per_gpu': B, 'global_batch': B * world, 'frames': T,
                        'classes': C, 'parallelism': 'dp%d' % world,
-                       'final_loss': float(loss)},
+                       'final_loss': float(loss.detach())},
             'roofline': {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': pmc_traffic(order, B, T),
