@@ -148,18 +148,22 @@ def cpu_baseline(T, order, seconds_budget=15.0):
 def pmc_traffic(order, B, T):
     """HBM bytes per lattice launch from the PMC passes committed under profiles/
     (r01_pmc_step_fetch_write.json / r01_pmc_lattice_fetch_write.json: separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs of bench.py / tools/bench_lattice.py at B=512, T'=334; FETCH_SIZE reads half of a 4 B/lane coalesced
+    FETCH_SIZE / WRITE_SIZE runs of bench.py (tools/pmc_summary.py) / tools/bench_lattice.py, T'=334; FETCH_SIZE reads half of a 4 B/lane coalesced
     stream on gfx950 - calibrated on log_softmax_fwd - so traffic = 2*FETCH + WRITE).
     bench.py cannot collect counters itself; the figure applies to the measured shape only."""
-    if B != 512 or T != 1000:
+    if T != 1000:
         return None
     k = 'lattice_fwbw_sl_kernel<3, 8, 1>' if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>'
     try:    # passes over bench.py itself (the lattice launch inside the training step)
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_step_fetch_write.json')))
-        e = pmc['kernels'][k]
+        if pmc.get('batch', 512) != B:
+            return None
+        e = next(v for n, v in pmc['kernels'].items() if k in n)
         return (2 * e['fetch_KB'] + e['write_KB']) * 1024.0
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, StopIteration, TypeError):
         pass
+    if B != 512:
+        return None
     try:    # passes over tools/bench_lattice.py (same shapes, kernel alone)
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_lattice_fetch_write.json')))
         return (2 * pmc['FETCH_SIZE'][k]['mean_KB'] + pmc['WRITE_SIZE'][k]['mean_KB']) * 1024.0
@@ -172,7 +176,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=512, help='utterances per GPU')
+    ap.add_argument('--batch', type=int, default=576,
+                    help='utterances per GPU (576 = 24 batch tiles of 24 rows: the persistent LSTM '
+                         'grid of 48 teams x 5 workgroups exactly)')
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--order', type=int, default=1, help='1 mono-char CTC, 2 bi-char CTC')
     ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS),
