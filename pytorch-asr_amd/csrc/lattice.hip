@@ -544,8 +544,11 @@ __device__ __forceinline__ float dpp_wave_sum(float v) {
 #define ASR_L2E 1.4426950408889634f
 #define ASR_LN2 0.6931471805599453f
 
+// waves_per_eu(6): <= 80 VGPRs, so THREE 8-wave workgroups fit a CU (two with the 89 the
+// compiler takes otherwise): batches of 513..768 utterances stay one wave of workgroups
 template <int K, int D, int FL>
-__global__ __launch_bounds__(1024) void lattice_fwbw_sl_kernel(FwbwParams p) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
+void lattice_fwbw_sl_kernel(FwbwParams p) {
     // FL == 1: C <= H, the per-step row flush is one store per lane;
     // FL == 0: runtime flush loop (large C, bandwidth-bound regime);
     // FL == 2: split scatter — phase 1 leaves the state posteriors gamma_f[n] in the
