@@ -197,8 +197,9 @@ int asr_lattice_grouped_forward_f32(
  * The caller supplies the input projection of every frame,
  *   gx [T,B,2,4H] f32, or bf16 with gx_bf16 != 0 (what a bf16 GEMM emits; halves its
  *      1.75 GB output at B=512) = x · W_ihᵀ   (direction-major, gate order i,f,g,o),
- * and the recurrent weights as bf16 (MFMA operands; accumulation, gates and
- * the cell state are fp32):  whh [2,4H,H] for the forward pass,
+ * and the recurrent weights as bf16 (MFMA operands; accumulation, gate arithmetic and
+ * the cell state are fp32; the gates SAVED for the backward pass are rounded to bf16):
+ * whh [2,4H,H] for the forward pass,
  * whhT [2,H,4H] (transposed) for the backward pass.
  * Utterance b is active at frame t iff t < lens[b]; padding frames emit zeros
  * and carry no gradient, which reproduces pack_padded_sequence semantics
@@ -209,8 +210,9 @@ int asr_lattice_grouped_forward_f32(
  *                      zero frame at both ends: h_{t-1} of the forward
  *                      direction is the slice [0][0:T], of the reverse
  *                      direction [1][2:T+2] — contiguous GEMM operands for dW_hh
- *   gates  [T,2,B,4,H] post-activation gates, csave [T,2,B,H] cell states:
- *                      saved by the forward pass for the backward pass
+ *   gates_bf16 [T,2,B,H,4] bf16 post-activation gates (one 8-byte record i,f,g,o per
+ *                      hidden unit), csave [T,2,B,H] f32 cell states: saved by the
+ *                      forward pass for the backward pass
  *   dy     [T,B,2,H]   gradient w.r.t. y; dy_shared != 0: [T,B,H], one gradient for
  *                      both directions (BatchRNN sums them, encoder_utils.py:112-117)
  *   dgates_bf16 [T,B,2,4H] bf16: gradient w.r.t. the gate pre-activations
@@ -223,13 +225,13 @@ int64_t asr_lstm_workspace_bytes(int B, int H);
 
 int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *whh_bf16,
                             const int32_t *lens, int T, int B, int H,
-                            float *y, void *y_bf16, float *gates, float *csave,
+                            float *y, void *y_bf16, void *gates_bf16, float *csave,
                             void *workspace, int64_t workspace_bytes,
                             void *stream);
 
 int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
                             const int32_t *lens, int T, int B, int H,
-                            const float *gates, const float *csave,
+                            const void *gates_bf16, const float *csave,
                             void *dgates_bf16,
                             void *workspace, int64_t workspace_bytes,
                             void *stream);

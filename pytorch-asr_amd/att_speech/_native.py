@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -240,7 +240,7 @@ def argmax_rows(x):
 
 def lstm_bidir_fwd(gx, whh_bf16, lens):
     """asr_lstm_bidir_fwd_bf16: gx [T,B,2,4H] f32 or bf16, whh [2,4H,H] bf16, lens [B] i32
-    -> (y [T,B,2,H] f32, y_bf16 [2,T+2,B,H], gates [T,2,B,4,H], csave [T,2,B,H])."""
+    -> (y [T,B,2,H] f32, y_bf16 [2,T+2,B,H], gates [T,2,B,H,4] bf16, csave [T,2,B,H])."""
     gx = _dev(gx, gx.dtype if gx.dtype == torch.bfloat16 else torch.float32, 'gx')
     whh_bf16 = _dev(whh_bf16, torch.bfloat16, 'whh')
     lens = _dev(lens, torch.int32, 'lens')
@@ -249,7 +249,7 @@ def lstm_bidir_fwd(gx, whh_bf16, lens):
     L = lib()
     y = torch.empty((T, B, 2, H), dtype=torch.float32, device=gx.device)
     ybf = torch.empty((2, T + 2, B, H), dtype=torch.bfloat16, device=gx.device)
-    gates = torch.empty((T, 2, B, 4, H), dtype=torch.float32, device=gx.device)
+    gates = torch.empty((T, 2, B, H, 4), dtype=torch.bfloat16, device=gx.device)
     csave = torch.empty((T, 2, B, H), dtype=torch.float32, device=gx.device)
     nbytes = L.asr_lstm_workspace_bytes(B, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=gx.device)

@@ -40,6 +40,29 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// The four post-activation gates of one (frame, direction, utterance, hidden unit) are
+// saved for the backward pass as ONE 8-byte record of four bf16 (i,f,g,o): a single
+// coalesced 8 B/lane store / load per element instead of four fp32 ones with stride H
+// (the saved gates were the recurrence's largest stream: 1.75 GB per layer at B=512).
+__device__ __forceinline__ u32x2 pack_gates(const float g[4]) {
+    const unsigned s0 = __builtin_bit_cast(unsigned short, (__bf16)g[0]);
+    const unsigned s1 = __builtin_bit_cast(unsigned short, (__bf16)g[1]);
+    const unsigned s2 = __builtin_bit_cast(unsigned short, (__bf16)g[2]);
+    const unsigned s3 = __builtin_bit_cast(unsigned short, (__bf16)g[3]);
+    u32x2 v;
+    v[0] = s0 | (s1 << 16);
+    v[1] = s2 | (s3 << 16);
+    return v;
+}
+__device__ __forceinline__ void unpack_gates(u32x2 v, float g[4]) {
+    const unsigned lo = v[0], hi = v[1];
+    g[0] = __builtin_bit_cast(float, lo << 16);
+    g[1] = __builtin_bit_cast(float, lo & 0xFFFF0000u);
+    g[2] = __builtin_bit_cast(float, hi << 16);
+    g[3] = __builtin_bit_cast(float, hi & 0xFFFF0000u);
+}
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // v_exp_f32 / v_rcp_f32 forms (about 1 ulp each): four instructions per
@@ -98,7 +121,7 @@ struct LstmFwdParams {
     float *cbuf;            // [2 dir][B][H]
     float *y;               // [T,B,2,H] per-direction outputs (zeros when inactive)
     __bf16 *ybf;            // [2,T+2,B,H] bf16 copy, frame t at index t+1 (zero frames at both ends)
-    float *gates;           // [T,2,B,4,H] post-activation gates (saved for backward)
+    u32x2 *gates;           // [T,2,B,H] records of 4 bf16 post-activation gates (saved for backward)
     float *csave;           // [T,2,B,H] cell state after the step
     int step;
 };
@@ -242,22 +265,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
             const size_t sidx = ((size_t)dir * B + b) * H + j;
             float *yo = p.y + (((size_t)t * B + b) * 2 + dir) * H + j;
             __bf16 *ybo = p.ybf + (((size_t)dir * (p.T + 2) + t + 1) * B + b) * H + j;
-            const size_t gsave = ((((size_t)t * 2 + dir) * B + b) * 4) * H + j;
             const size_t csv = (((size_t)t * 2 + dir) * B + b) * H + j;
             if (pact[e]) {
                 float pre[4], gt[4], c, h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pre[g] = g_lds[bt][g][row][col] + pgx[e][g];
                 lstm_cell_fwd(pre, pc[e], gt, c, h);
-                const float gi = gt[0], gf = gt[1], gg = gt[2], go = gt[3];
                 p.cbuf[sidx] = c;
                 hnext[frag_off(b, j, KS)] = (__bf16)h;
                 *yo = h;
                 *ybo = (__bf16)h;
-                p.gates[gsave] = gi;
-                p.gates[gsave + H] = gf;
-                p.gates[gsave + 2 * H] = gg;
-                p.gates[gsave + 3 * H] = go;
+                p.gates[csv] = pack_gates(gt);
                 p.csave[csv] = c;
             } else {
                 hnext[frag_off(b, j, KS)] = hprev[frag_off(b, j, KS)];
@@ -284,7 +302,7 @@ struct LstmBwdParams {
     const __bf16 *whhT;     // fragment-major pack of W_hhᵀ: [2 dir][H rows][4H cols]
     const int32_t *lens;
     int T, B, H;
-    const float *gates;     // [T,2,B,4,H]
+    const u32x2 *gates;     // [T,2,B,H] records of 4 bf16 (i,f,g,o)
     const float *csave;     // [T,2,B,H]
     __bf16 *dgbuf;          // [2 pingpong][2 dir] fragment-major [Bp x 4H]: dgates of the previous step
     float *dcbuf;           // [2 dir][B][H] carried dL/dc
@@ -337,9 +355,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdParams p) {
         const int bc = b < B ? b : B - 1;
         const int len = p.lens[bc];
         pact[e] = b < B && t < len;
-        const size_t gsave = ((((size_t)t * 2 + dir) * B + bc) * 4) * H + j;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pg[e][g] = p.gates[gsave + g * H];
+        unpack_gates(p.gates[(((size_t)t * 2 + dir) * B + bc) * H + j], pg[e]);
         pcs[e] = p.csave[(((size_t)t * 2 + dir) * B + bc) * H + j];
         const int tp = dir == 0 ? t - 1 : t + 1;
         const int tpc = tp < 0 ? 0 : (tp >= p.T ? p.T - 1 : tp);
@@ -520,10 +536,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         vy[e] = b < B ? (u32)((b * 2 + dir) * H + j) * 4u : OOBV;
         vyb[e] = b < B ? (u32)(((size_t)(dir * (T + 2) + 1) * B + b) * H + j) * 2u : OOBV;
         vcs[e] = b < B ? (u32)((dir * B + b) * H + j) * 4u : OOBV;
-        vg[e] = b < B ? (u32)((dir * B + b) * 4 * H + j) * 4u : OOBV;
+        vg[e] = b < B ? (u32)((dir * B + b) * H + j) * 8u : OOBV;
     }
     const u32 fgx = (u32)B * 8u * H * GXE, fy = (u32)B * 2u * H * 4u, fyb = (u32)B * H * 2u;
-    const u32 fcs = (u32)B * 2u * H * 4u, fg = (u32)B * 8u * H * 4u, H4b = (u32)H * 4u;
+    const u32 fcs = (u32)B * 2u * H * 4u, fg = (u32)B * 2u * H * 8u;
     const __amdgpu_buffer_rsrc_t gxR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(p.gx), 0, (int)((u32)T * fgx), 0x00020000);
     const __amdgpu_buffer_rsrc_t yR = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((u32)T * fy), 0x00020000);
@@ -561,11 +577,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
             __builtin_amdgcn_raw_buffer_store_b16(
                 (short)__builtin_bit_cast(unsigned short, (__bf16)soh[e]), ybR, vyb[e], ust * fyb, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sc[e]), csR, vcs[e], ust * fcs, 0);
-            const u32 vge = sact[e] ? vg[e] : OOBV;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sog[e][g]), gR, vge,
-                                                      ust * fg + (u32)g * H4b, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(pack_gates(sog[e]), gR, sact[e] ? vg[e] : OOBV,
+                                                  ust * fg, 0);
         }
     };
 
@@ -731,15 +744,15 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int b = b0 + e * 8 + wave;
-        vg[e] = (u32)((dir * B + bcl[e]) * 4 * H + j) * 4u;
+        vg[e] = (u32)((dir * B + bcl[e]) * H + j) * 8u;
         vcs[e] = (u32)((dir * B + bcl[e]) * H + j) * 4u;
         vdy[e] = (u32)(p.dy_shared ? bcl[e] * H + j : (bcl[e] * 2 + dir) * H + j) * 4u;
         vdg[e] = b < B ? (u32)((b * 2 + dir) * H4 + j) * 2u : OOBV;
     }
-    const u32 fg = (u32)B * 8u * H * 4u, fcs = (u32)B * 2u * H * 4u;
+    const u32 fg = (u32)B * 2u * H * 8u, fcs = (u32)B * 2u * H * 4u;
     const u32 fdy = (u32)B * H * 4u * (p.dy_shared ? 1u : 2u), fdg = (u32)B * 2u * H4 * 2u;
     const __amdgpu_buffer_rsrc_t gR = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.gates), 0, (int)((u32)T * fg), 0x00020000);
+        const_cast<u32x2 *>(p.gates), 0, (int)((u32)T * fg), 0x00020000);
     const __amdgpu_buffer_rsrc_t csR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.csave), 0, (int)((u32)T * fcs), 0x00020000);
     const __amdgpu_buffer_rsrc_t dyR = __builtin_amdgcn_make_buffer_rsrc(
@@ -755,8 +768,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
         const int tpc = tp < 0 ? 0 : (tp >= T ? T - 1 : tp);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) q.g[e][g] = ldf(gR, vg[e], (u32)t * fg + (u32)g * H * 4u);
+            unpack_gates(__builtin_amdgcn_raw_buffer_load_b64(gR, vg[e], (u32)t * fg, 0), q.g[e]);
             q.cp[e] = ldf(csR, vcs[e], (u32)tpc * fcs);
             q.dy[e] = ldf(dyR, vdy[e], (u32)t * fdy);
         }
@@ -982,13 +994,13 @@ extern "C" int64_t asr_lstm_workspace_bytes(int B, int H) {
 
 extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *whh_bf16,
                                        const int32_t *lens, int T, int B, int H,
-                                       float *y, void *y_bf16, float *gates,
+                                       float *y, void *y_bf16, void *gates_bf16,
                                        float *csave,
                                        void *workspace, int64_t workspace_bytes,
                                        void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0) return ASR_EINVAL;
     if (T == 0) return ASR_OK;
-    if (!gx || !whh_bf16 || !lens || !y || !y_bf16 || !gates || !csave || !workspace)
+    if (!gx || !whh_bf16 || !lens || !y || !y_bf16 || !gates_bf16 || !csave || !workspace)
         return ASR_EINVAL;
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -1000,7 +1012,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
     p.T = T; p.B = B; p.H = H;
     p.hbuf = (__bf16 *)workspace;
     p.cbuf = (float *)((char *)workspace + hbytes);
-    p.y = y; p.ybf = (__bf16 *)y_bf16; p.gates = gates; p.csave = csave;
+    p.y = y; p.ybf = (__bf16 *)y_bf16; p.gates = (u32x2 *)gates_bf16; p.csave = csave;
     zero_async(workspace, hbytes + cbytes, s);
     // the two pad frames of every direction of y_bf16
     for (int d = 0; d < 2; ++d) {
@@ -1048,13 +1060,13 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
 
 extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
                                        const int32_t *lens, int T, int B, int H,
-                                       const float *gates, const float *csave,
+                                       const void *gates_bf16, const float *csave,
                                        void *dgates_bf16,
                                        void *workspace, int64_t workspace_bytes,
                                        void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0) return ASR_EINVAL;
     if (T == 0) return ASR_OK;
-    if (!dy || !whhT_bf16 || !lens || !gates || !csave || !dgates_bf16 || !workspace)
+    if (!dy || !whhT_bf16 || !lens || !gates_bf16 || !csave || !dgates_bf16 || !workspace)
         return ASR_EINVAL;
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -1064,7 +1076,7 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const voi
     __bf16 *wpack = (__bf16 *)((char *)workspace + dbytes + cbytes);
     p.dy = dy; p.dy_shared = dy_shared; p.whhT = wpack; p.lens = lens;
     p.T = T; p.B = B; p.H = H;
-    p.gates = gates; p.csave = csave;
+    p.gates = (const u32x2 *)gates_bf16; p.csave = csave;
     p.dgbuf = (__bf16 *)workspace;
     p.dcbuf = (float *)((char *)workspace + dbytes);
     p.dgates = (__bf16 *)dgates_bf16;

@@ -115,7 +115,7 @@ def test_persistent_recurrence_is_bitwise_the_per_step_one(T, B, H, reps):
         ref = ref_cache[gxi.dtype]
         out = _run_native(gxi, whh, lens_d, dy, persist=True)
         for name, a, b in zip(('y', 'y_bf16', 'gates', 'csave', 'dgates'), out, ref):
-            if name == 'gates':                                         # [T,2,B,4,H]: defined on active frames
+            if name == 'gates':                                         # [T,2,B,H,4]: defined on active frames
                 m = act[:, None, :, None, None].expand_as(a)
                 a, b = a[m], b[m]
             assert not torch.isnan(a.float()).any(), name
