@@ -590,23 +590,33 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         }
         PSTAMP(0);
         __syncthreads();
-        // ---- h_{t-1} tile of the whole team: KS KiB, sc1 loads only
-        constexpr int CH = KS * 64, NI = (CH + 511) / 512;
-        u32x4 tmp[NI];
-        {
+        // ---- h_{t-1} tile of the team: the KS - 4 KiB of the OTHER workgroups come over
+        // sc1 loads; this workgroup's own 4 KiB are still in h_lds (staged there for the
+        // store of the previous step: the same bytes) and are copied LDS -> LDS
+        constexpr int CHO = (KS - 4) * 64, NI = (CHO + 511) / 512;
+        u32x4 tmp[NI > 0 ? NI : 1];
+        if constexpr (NI > 0) {
             const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H +
                                               (size_t)btile * KS * 512) * 2);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int ch = i * 512 + tid;       // lanes past the tile re-read its last chunk
-                tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(hres, base + (ch < CH ? ch : CH - 1) * 16,
+                const int co = i * 512 + tid;       // lanes past the tile re-read its last chunk
+                const int cc = co < CHO ? co : CHO - 1;
+                const int ko = cc >> 6, k = ko < 4 * jt ? ko : ko + 4;
+                tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(hres, base + (k * 64 + (cc & 63)) * 16,
                                                                0, ASR_SC1);
             }
         }
+        if (tid < 256)
+            reinterpret_cast<u32x4 *>(a_lds)[(4 * jt + (tid >> 6)) * 64 + (tid & 63)] =
+                reinterpret_cast<const u32x4 *>(h_lds)[tid];
+        if constexpr (NI > 0) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int ch = i * 512 + tid;
-            if (ch < CH) reinterpret_cast<u32x4 *>(a_lds)[ch] = tmp[i];
+            for (int i = 0; i < NI; ++i) {
+                const int co = i * 512 + tid;
+                const int ko = co >> 6, k = ko < 4 * jt ? ko : ko + 4;
+                if (co < CHO) reinterpret_cast<u32x4 *>(a_lds)[k * 64 + (co & 63)] = tmp[i];
+            }
         }
         __syncthreads();
         PSTAMP(1);
@@ -801,23 +811,38 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
         }
         PSTAMP(0);
         __syncthreads();
-        // ---- dgates_{prev step} rows of this batch tile, all 4H columns: 4*KS KiB, sc1 loads only
-        constexpr int CH = KS4 * 64, NI = (CH + 511) / 512;
-        u32x4 tmp[NI];
-        {
+        // ---- dgates_{prev step} rows of this batch tile, all 4H columns (4*KS KiB): the
+        // 16 KiB this workgroup produced itself are still in dg_lds (LDS -> LDS copy), the
+        // rest comes from the team mates over sc1 loads
+        constexpr int CHO = (KS4 - 16) * 64, NI = (CHO + 511) / 512;
+        u32x4 tmp[NI > 0 ? NI : 1];
+        if constexpr (NI > 0) {
             const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H4 +
                                               (size_t)btile * KS4 * 512) * 2);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int ch = i * 512 + tid;
-                tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(dres, base + (ch < CH ? ch : CH - 1) * 16,
+                const int co = i * 512 + tid;
+                const int cc = co < CHO ? co : CHO - 1;
+                const int kq = cc >> 6, g = kq / (KS - 4), r = kq - g * (KS - 4);
+                const int k = g * KS + (r < 4 * jt ? r : r + 4);
+                tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(dres, base + (k * 64 + (cc & 63)) * 16,
                                                                0, ASR_SC1);
             }
         }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int ch = i * 512 + tid;
-            if (ch < CH) reinterpret_cast<u32x4 *>(a_lds)[ch] = tmp[i];
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * 512 + tid, bi = c >> 6;         // bi = gate * 4 + kk
+            reinterpret_cast<u32x4 *>(a_lds)[((bi >> 2) * KS + 4 * jt + (bi & 3)) * 64 + (c & 63)] =
+                reinterpret_cast<const u32x4 *>(dg_lds)[c];
+        }
+        if constexpr (NI > 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int co = i * 512 + tid;
+                const int kq = co >> 6, g = kq / (KS - 4), r = kq - g * (KS - 4);
+                const int k = g * KS + (r < 4 * jt ? r : r + 4);
+                if (co < CHO) reinterpret_cast<u32x4 *>(a_lds)[k * 64 + (co & 63)] = tmp[i];
+            }
         }
         __syncthreads();
         PSTAMP(1);
