@@ -501,6 +501,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     unsigned *myctr = ctl.ctr + ((size_t)dir * ctl.nbt + btile) * 32;
     if (tid == 0) dead_s = 0;
     for (int i = tid; i < 2048; i += 512) h_lds[i] = (__bf16)0.f;       // padding rows stay 0
+    for (int i = tid; i < KS * 64; i += 512)                            // (the tile's too: never loaded)
+        reinterpret_cast<u32x4 *>(a_lds)[i] = u32x4{0u, 0u, 0u, 0u};
 
     bf16x8 fb[KS];
     {
@@ -593,7 +595,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         // ---- h_{t-1} tile of the team: the KS - 4 KiB of the OTHER workgroups come over
         // sc1 loads; this workgroup's own 4 KiB are still in h_lds (staged there for the
         // store of the previous step: the same bytes) and are copied LDS -> LDS
-        constexpr int CHO = (KS - 4) * 64, NI = (CHO + 511) / 512;
+        // (only the 2 * 8*NE chunks of a k-step that carry real batch rows move; the
+        // padding rows of the 32-row MFMA tile stay zero in LDS)
+        constexpr int RL = 8 * NE, CPK = 2 * RL;
+        constexpr int CHO = (KS - 4) * CPK, NI = (CHO + 511) / 512;
         u32x4 tmp[NI > 0 ? NI : 1];
         if constexpr (NI > 0) {
             const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H +
@@ -602,9 +607,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
             for (int i = 0; i < NI; ++i) {
                 const int co = i * 512 + tid;       // lanes past the tile re-read its last chunk
                 const int cc = co < CHO ? co : CHO - 1;
-                const int ko = cc >> 6, k = ko < 4 * jt ? ko : ko + 4;
-                tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(hres, base + (k * 64 + (cc & 63)) * 16,
-                                                               0, ASR_SC1);
+                const int ko = cc / CPK, q = cc - ko * CPK, k = ko < 4 * jt ? ko : ko + 4;
+                tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                    hres, base + (k * 64 + (q < RL ? q : q + (32 - RL))) * 16, 0, ASR_SC1);
             }
         }
         if (tid < 256)
@@ -614,8 +619,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int co = i * 512 + tid;
-                const int ko = co >> 6, k = ko < 4 * jt ? ko : ko + 4;
-                if (co < CHO) reinterpret_cast<u32x4 *>(a_lds)[k * 64 + (co & 63)] = tmp[i];
+                const int ko = co / CPK, q = co - ko * CPK, k = ko < 4 * jt ? ko : ko + 4;
+                if (co < CHO)
+                    reinterpret_cast<u32x4 *>(a_lds)[k * 64 + (q < RL ? q : q + (32 - RL))] = tmp[i];
             }
         }
         __syncthreads();
@@ -672,7 +678,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
             const u32x4 v = reinterpret_cast<const u32x4 *>(h_lds)[wave * 64 + lane];
             const unsigned off = (unsigned)(((((size_t)((step + 1) & 1) * 2 + dir) * Bp * H) +
                                              ((size_t)btile * KS + 4 * jt + wave) * 512 + lane * 8) * 2);
-            __builtin_amdgcn_raw_buffer_store_b128(v, hres, off, 0, ASR_SC1);
+            // padding rows are not handed over (nobody loads them)
+            __builtin_amdgcn_raw_buffer_store_b128(v, hres, (lane & 31) < 8 * NE ? off : 0xFFFFFFFFu,
+                                                   0, ASR_SC1);
         }
         PSTAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -721,6 +729,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
     unsigned *myctr = ctl.ctr + ((size_t)dir * ctl.nbt + btile) * 32;
     if (tid == 0) dead_s = 0;
     for (int i = tid; i < 8192; i += 512) dg_lds[i] = (__bf16)0.f;      // padding rows stay 0
+    for (int i = tid; i < KS4 * 64; i += 512)                           // (the tile's too: never loaded)
+        reinterpret_cast<u32x4 *>(a_lds)[i] = u32x4{0u, 0u, 0u, 0u};
 
     bf16x8 fb[KS];
     {
@@ -814,7 +824,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
         // ---- dgates_{prev step} rows of this batch tile, all 4H columns (4*KS KiB): the
         // 16 KiB this workgroup produced itself are still in dg_lds (LDS -> LDS copy), the
         // rest comes from the team mates over sc1 loads
-        constexpr int CHO = (KS4 - 16) * 64, NI = (CHO + 511) / 512;
+        // (real batch rows only, as in the forward kernel)
+        constexpr int RL = 8 * NE, CPK = 2 * RL;
+        constexpr int CHO = (KS4 - 16) * CPK, NI = (CHO + 511) / 512;
         u32x4 tmp[NI > 0 ? NI : 1];
         if constexpr (NI > 0) {
             const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H4 +
@@ -823,10 +835,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
             for (int i = 0; i < NI; ++i) {
                 const int co = i * 512 + tid;
                 const int cc = co < CHO ? co : CHO - 1;
-                const int kq = cc >> 6, g = kq / (KS - 4), r = kq - g * (KS - 4);
+                const int kq = cc / CPK, q = cc - kq * CPK, g = kq / (KS - 4), r = kq - g * (KS - 4);
                 const int k = g * KS + (r < 4 * jt ? r : r + 4);
-                tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(dres, base + (k * 64 + (cc & 63)) * 16,
-                                                               0, ASR_SC1);
+                tmp[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                    dres, base + (k * 64 + (q < RL ? q : q + (32 - RL))) * 16, 0, ASR_SC1);
             }
         }
 #pragma unroll
@@ -839,9 +851,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int co = i * 512 + tid;
-                const int kq = co >> 6, g = kq / (KS - 4), r = kq - g * (KS - 4);
+                const int kq = co / CPK, q = co - kq * CPK, g = kq / (KS - 4), r = kq - g * (KS - 4);
                 const int k = g * KS + (r < 4 * jt ? r : r + 4);
-                if (co < CHO) reinterpret_cast<u32x4 *>(a_lds)[k * 64 + (co & 63)] = tmp[i];
+                if (co < CHO)
+                    reinterpret_cast<u32x4 *>(a_lds)[k * 64 + (q < RL ? q : q + (32 - RL))] = tmp[i];
             }
         }
         __syncthreads();
@@ -903,7 +916,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
             const u32x4 v = reinterpret_cast<const u32x4 *>(dg_lds)[bi * 64 + lane];
             const unsigned off = (unsigned)(((((size_t)((step + 1) & 1) * 2 + dir) * Bp * H4) +
                                              ((size_t)btile * KS4 + g * KS + 4 * jt + kk) * 512 + lane * 8) * 2);
-            __builtin_amdgcn_raw_buffer_store_b128(v, dres, off, 0, ASR_SC1);
+            __builtin_amdgcn_raw_buffer_store_b128(v, dres, (lane & 31) < 8 * NE ? off : 0xFFFFFFFFu,
+                                                   0, ASR_SC1);
         }
         PSTAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
