@@ -25,6 +25,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 # pinned MIOpen solver choice for the conv layers that still go through torch
 # (see pytorch-asr_amd/miopen_db/README.md); must be set before MIOpen loads
 os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(ROOT, 'pytorch-asr_amd', 'miopen_db'))
+
+
+def pin_gemm_selection(local_rank):
+    """Library GEMM solutions measured fastest for this step's bf16 GEMM shapes (PyTorch
+    TunableOp results committed under pytorch-asr_amd/tunableop/, tuning OFF): the same
+    kind of pin as the MIOpen find-db above.  TunableOp reads `<name><device>.csv`, so
+    every rank gets its own copy.  Any PYTORCH_TUNABLEOP_* setting of the caller wins."""
+    src = os.path.join(ROOT, 'pytorch-asr_amd', 'tunableop', 'gfx950_b576.csv')
+    if any(k.startswith('PYTORCH_TUNABLEOP_') for k in os.environ) or not os.path.exists(src):
+        return
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix='asr_tunableop_')
+    shutil.copy(src, os.path.join(d, 'results%d.csv' % local_rank))
+    os.environ.update(PYTORCH_TUNABLEOP_ENABLED='1', PYTORCH_TUNABLEOP_TUNING='0',
+                      PYTORCH_TUNABLEOP_FILENAME=os.path.join(d, 'results.csv'))
 for p in (ROOT, os.path.join(ROOT, 'pytorch-asr_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -191,6 +207,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    pin_gemm_selection(local_rank)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
