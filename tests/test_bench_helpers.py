@@ -45,23 +45,26 @@ def test_pmc_traffic_reads_the_committed_summary():
     assert b.pmc_traffic(1, pmc['batch'], 999) is None
 
 
-def test_gemm_pin_respects_the_caller(monkeypatch):
+def test_gemm_pin_respects_the_caller():
     b = load(os.path.join(ROOT, 'bench.py'), 'bench_mod3')
-    for k in list(os.environ):
-        if k.startswith('PYTORCH_TUNABLEOP_'):
-            monkeypatch.delenv(k)
-    b.pin_gemm_selection(3)
-    assert os.environ['PYTORCH_TUNABLEOP_ENABLED'] == '1'
-    assert os.environ['PYTORCH_TUNABLEOP_TUNING'] == '0'
-    name = os.environ['PYTORCH_TUNABLEOP_FILENAME']
-    copy = name[:-len('.csv')] + '3.csv'                          # TunableOp appends the device
-    assert open(copy).read() == open(os.path.join(
-        ROOT, 'pytorch-asr_amd', 'tunableop', 'gfx950_b576.csv')).read()
-    for k in ('PYTORCH_TUNABLEOP_ENABLED', 'PYTORCH_TUNABLEOP_TUNING', 'PYTORCH_TUNABLEOP_FILENAME'):
-        monkeypatch.delenv(k)
-    monkeypatch.setenv('PYTORCH_TUNABLEOP_ENABLED', '0')
-    b.pin_gemm_selection(0)
-    assert 'PYTORCH_TUNABLEOP_FILENAME' not in os.environ
+    saved = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith('PYTORCH_TUNABLEOP_')}
+    try:
+        b.pin_gemm_selection(3)
+        assert os.environ['PYTORCH_TUNABLEOP_ENABLED'] == '1'
+        assert os.environ['PYTORCH_TUNABLEOP_TUNING'] == '0'
+        name = os.environ['PYTORCH_TUNABLEOP_FILENAME']
+        copy = name[:-len('.csv')] + '3.csv'                      # TunableOp appends the device
+        assert open(copy).read() == open(os.path.join(
+            ROOT, 'pytorch-asr_amd', 'tunableop', 'gfx950_b576.csv')).read()
+        for k in [k for k in os.environ if k.startswith('PYTORCH_TUNABLEOP_')]:
+            del os.environ[k]
+        os.environ['PYTORCH_TUNABLEOP_ENABLED'] = '0'             # any setting of the caller wins
+        b.pin_gemm_selection(0)
+        assert 'PYTORCH_TUNABLEOP_FILENAME' not in os.environ
+    finally:
+        for k in [k for k in os.environ if k.startswith('PYTORCH_TUNABLEOP_')]:
+            del os.environ[k]
+        os.environ.update(saved)
 
 
 def test_pmc_summary_tool(tmp_path, monkeypatch):
