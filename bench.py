@@ -31,14 +31,15 @@ def pin_gemm_selection(local_rank):
     """Library GEMM solutions measured fastest for this step's bf16 GEMM shapes (PyTorch
     TunableOp results committed under pytorch-asr_amd/tunableop/, tuning OFF): the same
     kind of pin as the MIOpen find-db above.  TunableOp reads `<name><device>.csv`, so
-    every rank gets its own copy.  Any PYTORCH_TUNABLEOP_* setting of the caller wins."""
+    every rank gets its own copy (in its own temporary directory).  Any PYTORCH_TUNABLEOP_* setting of the caller wins."""
     src = os.path.join(ROOT, 'pytorch-asr_amd', 'tunableop', 'gfx950_b576.csv')
     if any(k.startswith('PYTORCH_TUNABLEOP_') for k in os.environ) or not os.path.exists(src):
         return
     import shutil
     import tempfile
     d = tempfile.mkdtemp(prefix='asr_tunableop_')
-    shutil.copy(src, os.path.join(d, 'results%d.csv' % local_rank))
+    for dev_ordinal in sorted({0, local_rank}):      # ordinal 0 too: launchers that mask devices per rank
+        shutil.copy(src, os.path.join(d, 'results%d.csv' % dev_ordinal))
     os.environ.update(PYTORCH_TUNABLEOP_ENABLED='1', PYTORCH_TUNABLEOP_TUNING='0',
                       PYTORCH_TUNABLEOP_FILENAME=os.path.join(d, 'results.csv'))
 for p in (ROOT, os.path.join(ROOT, 'pytorch-asr_amd')):
