@@ -86,7 +86,7 @@ class LmFst(object):
         neps = np.bincount(self.src[self.ilabel == 0], minlength=self._n).astype(np.int64)
         self.ptr_ne = self.ptr[:-1] + neps
         self._isyms, self._osyms = isymbols, osymbols
-        self._eps_rank = None
+        self._eps_rank = False          # False: not computed yet; None: the epsilon graph has a cycle
 
     # ---- pywrapfst-like surface -------------------------------------------
     def start(self):
@@ -120,7 +120,7 @@ class LmFst(object):
     def eps_rank(self):
         """rank[s] = length of the longest epsilon path ending in s; every epsilon arc
         goes from a lower to a higher rank.  None if the epsilon graph has a cycle."""
-        if self._eps_rank is None:
+        if self._eps_rank is False:
             eps = self.ilabel == 0
             es, ed = self.src[eps], self.dst[eps]
             rank = np.zeros(self._n, np.int64)
@@ -138,8 +138,8 @@ class LmFst(object):
                     indeg[d] -= 1
                     if indeg[d] == 0:
                         ready.append(d)
-            self._eps_rank = (rank if seen == self._n else None,)
-        return self._eps_rank[0]
+            self._eps_rank = rank if seen == self._n else None
+        return self._eps_rank
 
     # ---- text format ---------------------------------------------------------
     @classmethod
