@@ -8,16 +8,29 @@ own throughput definition, sum(feature_lens) / step_time (trainer.py:292-298).
 N > 1: one process per GPU (torch.distributed.run), utterance-sharded data
 parallelism, one RCCL all-reduce of the flat gradient bucket per step.
 
+`python bench.py --gpus N` without WORLD_SIZE in the environment starts the N ranks
+itself (a `torch.distributed.run` child process, before anything touches the GPU),
+relays rank 0's JSON line and exits with the child's code.
+
 Prints ONE JSON line on rank 0 (see the contract in the task statement), with
-  roofline     — the lattice forward-backward scan kernel, HBM-bound, timed live
-                 with events on the stream it is launched on;
-  cpu_baseline — the same step on the host cores (torch-CPU encoder + the CPU
-                 oracle for the lattice), bounded sample, N = 1 only.
+  roofline        — the lattice forward-backward scan kernel of the step, HBM-bound,
+                    timed live with events on the stream it is launched on;
+  roofline_bichar — the same kernel on the bi-char numerator (C = 2401, B = 512),
+                    launched alone after the timed region (N = 1 only);
+  roofline_mfma   — dense flops of the step / step time / 2.5 PFLOP/s (bf16 dense peak);
+  loss_delta      — |loss_gpu - loss_cpu| / |loss_cpu| of one small batch, product
+                    model on the GPU vs the fp32 CPU composition with the same weights
+                    (end to end, and decoder + lattice on identical encoder output);
+  cpu_baseline    — the same step on the host cores (torch-CPU encoder + the CPU
+                    oracle for the lattice), bounded sample, N = 1 only.
 """
 import argparse
 import contextlib
+import copy
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -52,6 +65,7 @@ import torch.distributed as dist        # noqa: E402
 
 _STDOUT = sys.stdout
 HBM_PEAK_GBPS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0               # MI355X_MICROARCH.md: bf16 MFMA ~2.5 PF dense
 S = 49                                  # egs/wsj/vocabulary.txt
 
 
@@ -100,24 +114,58 @@ def lattice_algorithmic_bytes(enc_lens, C, label_lens, n_arcs):
     return int((4 * tl * (3 * C + 2 * ns) + 24 * np.asarray(n_arcs, np.int64) + 4 * ns).sum())
 
 
-def cpu_baseline(T, order, seconds_budget=15.0):
+def step_flops(B, T, C, in_feats=40, H=320, layers=4):
+    """Dense multiply-add flops of one training step (SURVEY.md §8d 'Algorithmic
+    flops'): both convolutions, the 4 BiLSTM layers (input + recurrent products)
+    and the class projection; training = 3 x forward (fwd, dgrad, wgrad)."""
+    t1 = T + 2 * 6 - 7 + 1                      # conv1: k 7x7, stride (1,2), pad (6,0)
+    f1 = (in_feats - 7) // 2 + 1
+    t2 = (t1 - 7) // 3 + 1                      # conv2: k 7x7, stride (3,1)
+    f2 = f1 - 7 + 1
+    fwd = 2.0 * B * 32 * t1 * f1 * 49 + 2.0 * B * 32 * t2 * f2 * 32 * 49
+    rnn_in = 32 * f2
+    for l in range(layers):
+        fwd += 2 * 2.0 * t2 * B * 4 * H * ((rnn_in if l == 0 else H) + H)
+    fwd += 2.0 * t2 * B * H * C
+    return 3.0 * fwd
+
+
+class _OracleLattice(torch.autograd.Function):
+    """PathLogSumExp evaluated by oracle/lattice_oracle.c (the checker)."""
+
+    @staticmethod
+    def forward(ctx, lp, lens, mats):
+        from oracle import oracle
+        r = oracle.path_logsumexp(lp.detach().numpy(), lens.numpy(),
+                                  [m.numpy() for m in mats])
+        ctx.grads = torch.from_numpy(r['grad'])
+        return torch.from_numpy(r['logZ'])
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[None, :, None] * ctx.grads, None, None
+
+
+def _cpu_loss(model, gg, enc, elens, texts, llens):
+    """FSTDecoder.forward (advanced_decoder.py:454-534) in fp32 torch-CPU ops with
+    the oracle lattice, given the encoder output."""
+    logits = model.decoder.fc(enc)
+    lp = torch.log_softmax(logits, -1)
+    mx = lp.max(-1, keepdim=True)[0].detach()
+    mask = (torch.arange(lp.size(0))[:, None] < elens[None, :]).float()
+    mats = gg.get_training_matrices_batch(texts, llens)
+    num = -_OracleLattice.apply(lp - mx, elens, mats)
+    return (num - (mx.squeeze(-1) * mask).sum(0)).sum()
+
+
+def cpu_baseline(T, order, dev=None, seconds_budget=15.0):
     """The same training step on the host: torch-CPU encoder/projection +
-    oracle/lattice_oracle.c for the lattice (kind 'port'), small batch."""
+    oracle/lattice_oracle.c for the lattice (kind 'port'), small batch.  With
+    `dev`: also the loss delta of that batch between the product model on the
+    GPU and this fp32 CPU composition (same weights, before any update).
+    Returns (cpu_baseline dict, loss_delta dict or None)."""
     from att_speech.models import SpeechModel
     from att_speech import fst_utils
-    from oracle import oracle
-
-    class OracleLattice(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, lp, lens, mats):
-            r = oracle.path_logsumexp(lp.detach().numpy(), lens.numpy(),
-                                      [m.numpy() for m in mats])
-            ctx.grads = torch.from_numpy(r['grad'])
-            return torch.from_numpy(r['logZ'])
-
-        @staticmethod
-        def backward(ctx, g):
-            return g[None, :, None] * ctx.grads, None, None
 
     # the box's CPU share for one GPU is 16 cores; os.cpu_count() reports the
     # whole host and oversubscribing it is pathologically slow
@@ -136,16 +184,30 @@ def cpu_baseline(T, order, seconds_budget=15.0):
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     gg = fst_utils.CTCGraphGen(context_order=order, num_symbols=S)
 
+    delta = None
+    if dev is not None:
+        gpu_model = copy.deepcopy(model).to(dev)
+        with torch.no_grad():
+            enc_c, elens = model.encoder(feats, lens, None)
+            loss_cpu = float(_cpu_loss(model, gg, enc_c, elens, texts, llens))
+            loss_gpu = float(gpu_model(feats.to(dev), lens, None, texts, llens)['loss'])
+            enc_g, elens_g = gpu_model.encoder(feats.to(dev), lens, None)
+            loss_dec_gpu = float(gpu_model.decoder(enc_g, elens_g, texts, llens)['loss'])
+            loss_dec_cpu = float(_cpu_loss(model, gg, enc_g.float().cpu(), elens, texts, llens))
+        delta = {
+            'end_to_end_rel': abs(loss_gpu - loss_cpu) / abs(loss_cpu),
+            'decoder_lattice_rel': abs(loss_dec_gpu - loss_dec_cpu) / abs(loss_dec_cpu),
+            'loss_gpu': loss_gpu, 'loss_cpu': loss_cpu,
+            'batch': '%d x %d frames, same weights; end_to_end = bf16-operand encoder on '
+                     'the GPU vs fp32 torch-CPU encoder; decoder_lattice = projection + '
+                     'log-softmax + lattice on the SAME (GPU) encoder output, fp32 both '
+                     'sides (north_star bound 1e-4)' % (B, T)}
+        del gpu_model
+
     def step():
         opt.zero_grad()
         enc, elens = model.encoder(feats, lens, None)
-        logits = model.decoder.fc(enc)
-        lp = torch.log_softmax(logits, -1)
-        mx = lp.max(-1, keepdim=True)[0].detach()
-        mask = (torch.arange(lp.size(0))[:, None] < elens[None, :]).float()
-        mats = gg.get_training_matrices_batch(texts, llens)
-        num = -OracleLattice.apply(lp - mx, elens, mats)
-        loss = (num - (mx.squeeze(-1) * mask).sum(0)).sum()
+        loss = _cpu_loss(model, gg, enc, elens, texts, llens)
         loss.backward()
         opt.step()
         return float(loss)
@@ -156,10 +218,95 @@ def cpu_baseline(T, order, seconds_budget=15.0):
         step()
         n += 1
     dt = (time.time() - t0) / n
-    return dict(value=float(lens.sum()) / dt, unit='frames/s', cores=cores, kind='port',
-                sample='%d steps of the same train step at B=%d x %d frames on the host '
-                       '(torch-CPU encoder + oracle/lattice_oracle.c lattice, 1 thread)'
-                       % (n, B, T))
+    base = dict(value=float(lens.sum()) / dt, unit='frames/s', cores=cores, kind='port',
+                sample='%d steps of the same train step at B=%d x %d frames on the host: '
+                       'torch-CPU conv/BiLSTM/projection on %d threads (the part that bounds '
+                       'it) + oracle/lattice_oracle.c lattice on 1 thread'
+                       % (n, B, T, cores))
+    return base, delta
+
+
+def bichar_numerator_roofline(dev, B=512, Tp=334, iters=10):
+    """The alpha/beta scan alone on the bi-char numerator (ctc_bi shape: C = 2401,
+    L_b = 100 - 2 (b mod 16), all utterances Tp frames): average launch time from
+    events on the launch stream / SURVEY.md §8d algorithmic bytes."""
+    from att_speech import _native, fst_utils
+    C = S * S
+    _, _, texts, llens = synthetic_batch(B, 3 * Tp - 2, 0, 2)
+    gg = fst_utils.CTCGraphGen(context_order=2, num_symbols=S)
+    mats = gg.get_training_matrices_batch(texts, llens)
+    n_arcs = (mats[2] > -1e19).sum((1, 2)).numpy()
+    g = _native.Graph(mats, dev)
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    lp = _native.log_softmax_fwd(torch.randn(Tp, B, C, device=dev, generator=gen), C)
+    tl = torch.full((B,), Tp, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        _native.lattice_fwbw(lp, tl, g)
+    ev = []
+    _native.EVENT_HOOK = ev
+    try:
+        for _ in range(iters):
+            _native.lattice_fwbw(lp, tl, g)
+    finally:
+        _native.EVENT_HOOK = None
+    torch.cuda.synchronize()
+    ms = float(np.mean([s.elapsed_time(e) for (s, e) in ev]))
+    alg = lattice_algorithmic_bytes(np.full(B, Tp), C, llens.numpy(), n_arcs)
+    ach = alg / (ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan), bi-char numerator '
+                                      'C=2401 B=%d T\'=%d' % (B, Tp),
+            'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
+            'traffic': None, 'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': ms}
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` with no rank environment: start the N ranks as a
+    child `torch.distributed.run` (this process has not touched the GPU and never
+    will), relay rank 0's JSON line, exit with the child's return code."""
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, universal_newlines=True)
+    line = None
+    for out in proc.stdout:
+        out = out.strip()
+        if out.startswith('{') and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, file=_STDOUT, flush=True)
+    elif rc == 0:
+        rc = 1
+    sys.exit(rc)
+
+
+def dry_run(a, world, rank):
+    """Launcher rehearsal without a GPU (tests/test_bench_helpers.py): gloo ranks,
+    the same barrier / max-over-ranks timing / single JSON line, no model."""
+    if world > 1:
+        dist.init_process_group('gloo')
+    t0 = time.time()
+    for _ in range(a.steps):
+        time.sleep(0.001)
+    t = torch.tensor([time.time() - t0], dtype=torch.float64)
+    units = torch.tensor([float(a.batch * a.frames)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({'metric': 'launcher dry run', 'dry_run': True, 'n_gpus': world,
+                          'steps': a.steps, 'warmup': a.warmup,
+                          'value': float(units) * a.steps / float(t)}), file=_STDOUT, flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def pmc_traffic(order, B, T):
@@ -203,18 +350,26 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hooks', action='store_true',
                     help='leave out GradientClipping / PolyakDecay (recipe hooks)')
+    ap.add_argument('--no-extra', action='store_true',
+                    help='leave out the bi-char numerator roofline launch')
+    ap.add_argument('--dry-run-launcher', action='store_true', help=argparse.SUPPRESS)
     a = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        self_launch(a, sys.argv[1:])             # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if a.dry_run_launcher:
+        return dry_run(a, world, rank)
     pin_gemm_selection(local_rank)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
 
     from att_speech import _native, fst_utils
     from att_speech.dp import FlatGradBucket, broadcast_parameters, train_step
@@ -248,10 +403,15 @@ def main():
 
     # the hooks of the recipe that touch gradients / parameters every step
     # (egs/wsj/yamls/ctc.yaml:90-103): global-norm clipping incl. skip-step (it
-    # sees the all-reduced gradient) and the Polyak average of the state_dict
+    # sees the all-reduced gradient) and the Polyak average of the state_dict.
+    # The recipe's thresholds (clip 1e4, skip 1e5) are for its global batch of 16
+    # utterances and a loss SUMMED over utterances: they are scaled with the
+    # global batch / 16 here, otherwise every step of a large batch is skipped.
     hooks = []
+    clip_scale = B * world / 16.0
     if not a.no_hooks:
-        hooks = [GradientClipping(clip_norm=10000.0, skip_step_norm=100000.0),
+        hooks = [GradientClipping(clip_norm=10000.0 * clip_scale,
+                                  skip_step_norm=100000.0 * clip_scale),
                  PolyakDecay(decay_rates=[0.9998])]
         for h in hooks:
             h.pre_run(model, opt)
@@ -267,12 +427,15 @@ def main():
             finally:
                 _native.EVENT_HOOK = None
     fwd = _Recorder()
+    skipped = []
 
     def step(record=False):
         fwd.on = record
         with contextlib.redirect_stdout(sys.stderr):     # hooks print like the reference; stdout is the JSON line
-            out, _ = train_step(model, opt, ((feats_d, lens, None, texts, llens), {}),
-                                hooks=hooks, bucket=bucket, forward=fwd)
+            out, skip = train_step(model, opt, ((feats_d, lens, None, texts, llens), {}),
+                                   hooks=hooks, bucket=bucket, forward=fwd)
+        if record:
+            skipped.append(bool(skip))
         return out['loss']
 
     def fence():
@@ -287,9 +450,12 @@ def main():
         if rank == 0:
             print('[bench %6.1fs] %s' % (time.time() - t_start, msg), file=sys.stderr, flush=True)
 
+    loss0 = None
     for i in range(a.warmup):
-        step()
+        l = step()
         torch.cuda.synchronize()
+        if loss0 is None:
+            loss0 = float(l.detach())
         progress('warmup step %d done' % i)
     fence()
     t0 = time.time()
@@ -297,6 +463,9 @@ def main():
         loss = step(record=True)
     fence()
     dt = time.time() - t0
+    # every timed step must have taken its optimizer step (work skipped inside the
+    # timed region would invalidate the number)
+    assert not any(skipped), 'optimizer step skipped in %d of %d timed steps' % (sum(skipped), len(skipped))
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -305,12 +474,19 @@ def main():
     if world > 1:
         dist.all_reduce(frames, op=dist.ReduceOp.SUM)
     total_frames = float(frames.item())
+    lstm_err = getattr(_native, 'lstm_check_errors', None)
+    if lstm_err is not None:
+        lstm_err()                               # raises if a persistent-LSTM hand-off timed out
 
     if rank == 0:
         lat_ms = [s.elapsed_time(e) for (s, e) in lat_events]
         lat_ms = float(np.mean(lat_ms)) if lat_ms else float('nan')
         alg = lattice_algorithmic_bytes(enc_lens, C, llens.numpy(), n_arcs)
         achieved = alg / (lat_ms * 1e-3) / 1e9
+        flops = step_flops(B, T, C)
+        tflops = flops * world * a.steps / dt / 1e12
+        hook_txt = '' if a.no_hooks else ('GradientClipping(clip %g, skip %g = recipe x global_batch/16)'
+                                          '+PolyakDecay+' % (1e4 * clip_scale, 1e5 * clip_scale))
         res = {
             'metric': 'CTC train-step frames/sec',
             'value': total_frames * a.steps / dt,
@@ -324,21 +500,32 @@ def main():
                                    'synthetic 40-dim x %d-frame fbank'
                                    % ('mono' if order == 1 else 'bi',
                                       a.workload or ('ctc' if order == 1 else 'ctc_bi'),
-                                      '' if a.no_hooks else 'GradientClipping+PolyakDecay+', T),
+                                      hook_txt, T),
                        'batch_per_gpu': B, 'global_batch': B * world, 'frames': T,
                        'classes': C, 'parallelism': 'dp%d' % world,
-                       'final_loss': float(loss.detach())},
+                       'optimizer_steps': len(skipped) - sum(skipped),
+                       'first_loss': loss0, 'final_loss': float(loss.detach())},
             'roofline': {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': pmc_traffic(order, B, T),
                          'algorithmic_bytes_per_launch': alg,
                          'avg_launch_ms': lat_ms},
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'whole step (conv + BiLSTM + projection, fwd+bwd)',
+                              'achieved': tflops, 'peak': MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
+                              'frac': tflops / (MFMA_PEAK_TFLOPS * world),
+                              'flops_per_step_per_gpu': flops},
         }
+        if world == 1 and not a.no_extra:
+            del feats_d
+            torch.cuda.empty_cache()
+            progress('bi-char numerator roofline launch')
+            res['roofline_bichar'] = bichar_numerator_roofline(dev)
         if world == 1 and not a.no_cpu_baseline and a.workload != 'ctcg_bi_cde':
-            progress('timing the CPU baseline (about 20 s)')
-            res['cpu_baseline'] = cpu_baseline(T, order)
+            progress('loss delta + timing the CPU baseline (about 25 s)')
+            res['cpu_baseline'], res['loss_delta'] = cpu_baseline(T, order, dev)
         else:
             res['cpu_baseline'] = None
+            res['loss_delta'] = None
         print(json.dumps(res), file=_STDOUT, flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -220,6 +220,13 @@ int asr_lattice_grouped_forward_f32(
  *                      with dense GEMMs (bf16 operands, fp32 accumulation)
  * workspace: asr_lstm_workspace_bytes(B, H) bytes.  Hidden sizes built:
  * 64, 128, 256, 320, 384, 512, 768 (ASR_EUNSUPPORTED otherwise).
+ *   err_flag  optional device word owned by the caller (never cleared by the library).
+ *             The persistent recurrence hands tiles between co-resident workgroups with
+ *             bounded spins; if a spin bound expires (another stream's kernel kept a team
+ *             mate off the device) the kernel stores 1 here and poisons its outputs with
+ *             NaN instead of hanging.  A caller that reads a non-zero word must discard
+ *             the step (att_speech._native.lstm_check_errors raises).  Debug knob:
+ *             ASR_LSTM_SPIN_LIMIT=<n> overrides the bound (0 forces the timeout).
  */
 int64_t asr_lstm_workspace_bytes(int B, int H);
 
@@ -227,14 +234,14 @@ int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *whh_bf16,
                             const int32_t *lens, int T, int B, int H,
                             float *y, void *y_bf16, void *gates_bf16, float *csave,
                             void *workspace, int64_t workspace_bytes,
-                            void *stream);
+                            uint32_t *err_flag, void *stream);
 
 int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
                             const int32_t *lens, int T, int B, int H,
                             const void *gates_bf16, const float *csave,
                             void *dgates_bf16,
                             void *workspace, int64_t workspace_bytes,
-                            void *stream);
+                            uint32_t *err_flag, void *stream);
 
 /*
  * BatchNorm2d + Hardtanh(lo, hi) fused over the [B, C, H, W] output of a

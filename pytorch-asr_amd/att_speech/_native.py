@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -47,8 +47,8 @@ _SIGNATURES = {
     'asr_lattice_grouped_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i] + [_vp] * 8 +
                                         [_f, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_workspace_bytes': (_i64, [_i, _i]),
-    'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'asr_bn_act_workspace_bytes': (_i64, [_i]),
     'asr_bn_act_fwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _i64, _vp]),
@@ -238,6 +238,31 @@ def argmax_rows(x):
     return out
 
 
+_LSTM_ERR = {}      # device index -> int32[1] timeout word of the persistent recurrence
+
+
+def _lstm_err_flag(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    f = _LSTM_ERR.get(idx)
+    if f is None:
+        f = _LSTM_ERR[idx] = torch.zeros(1, dtype=torch.int32, device=device)
+    return f
+
+
+def lstm_check_errors():
+    """Raise if a hand-off of the persistent BiLSTM recurrence timed out since the last
+    check (csrc/lstm.hip team_wait: the kernel then poisons its outputs with NaN; the
+    step must be discarded).  One 4-byte read-back per device; `dp.train_step` calls it
+    once per step."""
+    for idx, f in _LSTM_ERR.items():
+        if int(f.item()) != 0:
+            f.zero_()
+            raise RuntimeError(
+                'persistent BiLSTM recurrence: a team hand-off timed out on cuda:%d (another '
+                "stream's kernel kept a team mate off the device?); outputs of that call are "
+                'NaN. Set ASR_LSTM_PERSIST=0 to use one launch per time step.' % idx)
+
+
 def lstm_bidir_fwd(gx, whh_bf16, lens):
     """asr_lstm_bidir_fwd_bf16: gx [T,B,2,4H] f32 or bf16, whh [2,4H,H] bf16, lens [B] i32
     -> (y [T,B,2,H] f32, y_bf16 [2,T+2,B,H], gates [T,2,B,H,4] bf16, csave [T,2,B,H])."""
@@ -256,7 +281,7 @@ def lstm_bidir_fwd(gx, whh_bf16, lens):
     check(L.asr_lstm_bidir_fwd_bf16(_p(gx), int(gx.dtype == torch.bfloat16), _p(whh_bf16),
                                     _p(lens), T, B, H, _p(y),
                                     _p(ybf), _p(gates), _p(csave), _p(ws), nbytes,
-                                    _stream()), 'asr_lstm_bidir_fwd_bf16')
+                                    _p(_lstm_err_flag(gx.device)), _stream()), 'asr_lstm_bidir_fwd_bf16')
     return y, ybf, gates, csave
 
 
@@ -274,7 +299,8 @@ def lstm_bidir_bwd(dy, whhT_bf16, lens, gates, csave):
     nbytes = L.asr_lstm_workspace_bytes(B, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     check(L.asr_lstm_bidir_bwd_bf16(_p(dy), int(shared), _p(whhT_bf16), _p(lens), T, B, H,
-                                    _p(gates), _p(csave), _p(dgates), _p(ws), nbytes, _stream()),
+                                    _p(gates), _p(csave), _p(dgates), _p(ws), nbytes,
+                                    _p(_lstm_err_flag(dy.device)), _stream()),
           'asr_lstm_bidir_bwd_bf16')
     return dgates
 

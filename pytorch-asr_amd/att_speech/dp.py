@@ -89,9 +89,9 @@ def train_step(model, optimizer, batch_args, hooks=(), bucket=None, current_iter
         else fwd(**batch_args)
     loss = loss_dict['loss']
     skip = False
-    for h in hooks:
-        skip = bool(h.pre_backward(model=model, optimizer=optimizer,
-                                   current_iteration=current_iteration, loss=loss)) or skip
+    for h in hooks:        # `skip or hook(...)`: hooks behind one that asked to skip are not called (trainer.py:241-248)
+        skip = skip or bool(h.pre_backward(model=model, optimizer=optimizer,
+                                           current_iteration=current_iteration, loss=loss))
     if bucket is not None:
         bucket.zero_()
     else:
@@ -102,8 +102,11 @@ def train_step(model, optimizer, batch_args, hooks=(), bucket=None, current_iter
     for h in hooks:
         if hasattr(h, 'bucket'):
             h.bucket = bucket
-        skip = bool(h.post_backward(model=model, optimizer=optimizer,
-                                    current_iteration=current_iteration, loss=loss)) or skip
+        skip = skip or bool(h.post_backward(model=model, optimizer=optimizer,
+                                            current_iteration=current_iteration, loss=loss))
+    if loss.is_cuda:
+        from att_speech import _native
+        _native.lstm_check_errors()      # a timed-out hand-off left NaNs: raise before they reach the weights
     if not skip:
         optimizer.step()
     for h in hooks:

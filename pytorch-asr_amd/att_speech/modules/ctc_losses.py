@@ -126,5 +126,8 @@ def ctc_loss(acts, labels, act_lens, label_lens,
     losses = ctc_fst_loss(acts, labels, act_lens, label_lens,
                           num_symbols=acts.size(2), context_order=1,
                           normalize_by_dim=None)
+    # an utterance with no feasible alignment: the lattice returns -neg_inf-sized values,
+    # F.ctc_loss(zero_infinity=False) returns inf (and the mean with it)
+    losses = torch.where(losses >= 5e19, torch.full_like(losses, float('inf')), losses)
     tl = torch.as_tensor(label_lens).to(losses.device, losses.dtype).clamp(min=1)
     return (losses / tl).mean()

@@ -9,6 +9,7 @@ one) and lets the input projection run as one dense [T*B, F] GEMM."""
 from __future__ import division, print_function
 
 import inspect
+import warnings
 
 import torch
 from torch import nn
@@ -81,9 +82,18 @@ class BatchRNN(nn.Module):
 
     def _use_native(self, x):
         # the MI355X path: hand-written recurrence kernels (csrc/lstm.hip)
-        return (x.is_cuda and isinstance(self.rnn, nn.LSTM) and self.bidirectional
-                and self.hidden_size in (64, 128, 256, 320, 384, 512, 768)
-                and not self.rnn.bias)
+        native = (isinstance(self.rnn, nn.LSTM) and self.bidirectional
+                  and self.hidden_size in (64, 128, 256, 320, 384, 512, 768)
+                  and not self.rnn.bias)
+        if x.is_cuda and not native and not getattr(self, '_warned', False):
+            self._warned = True
+            warnings.warn(
+                'BatchRNN(%s, hidden %d, bidirectional=%s): no hand-written recurrence for this '
+                'layer (built: bias-free bidirectional LSTM, hidden 64/128/256/320/384/512/768); '
+                'running torch nn.%s (MIOpen) instead' % (
+                    type(self.rnn).__name__, self.hidden_size, self.bidirectional,
+                    type(self.rnn).__name__))
+        return x.is_cuda and native
 
     def forward(self, x, lens, speakers=None):
         """x [T,B,F] padded, lens [B] (CPU int, sorted descending)."""

@@ -986,7 +986,7 @@ inline int64_t plane_rows(int B) {
 
 template <typename P>
 bool launch_persist(void (*const kerns[3])(P, LstmTeamCtl), const P &p, int B, int H,
-                    size_t lds_need, unsigned *ctl_words, hipStream_t s) {
+                    size_t lds_need, unsigned *ctl_words, unsigned *err_flag, hipStream_t s) {
     const int njt = H / 64;
     const int cus = cu_count();
     if ((H % 64) != 0 || njt < 1 || cus < 2 * njt || lds_need > 160 * 1024) return false;
@@ -1006,8 +1006,9 @@ bool launch_persist(void (*const kerns[3])(P, LstmTeamCtl), const P &p, int B, i
     const int max_bt = cus / (2 * njt);
     LstmTeamCtl ctl;
     ctl.ctr = ctl_words + 64;
-    ctl.err = ctl_words;
+    ctl.err = err_flag ? err_flag : ctl_words;
     ctl.spin_limit = 1u << 18;
+    if (const char *e = getenv("ASR_LSTM_SPIN_LIMIT")) ctl.spin_limit = (unsigned)strtoul(e, nullptr, 10);
     ctl.nbt = nbt;
     ctl.rows = (size_t)plane_rows(B);
     for (int bt0 = 0; bt0 < nbt; bt0 += max_bt) {
@@ -1045,7 +1046,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
                                        float *y, void *y_bf16, void *gates_bf16,
                                        float *csave,
                                        void *workspace, int64_t workspace_bytes,
-                                       void *stream) {
+                                       uint32_t *err_flag, void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0) return ASR_EINVAL;
     if (T == 0) return ASR_OK;
     if (!gx || !whh_bf16 || !lens || !y || !y_bf16 || !gates_bf16 || !csave || !workspace)
@@ -1085,7 +1086,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
         const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (1ull << 32) &&
                             (uint64_t)2 * (T + 2) * B * H * 2 < (1ull << 32);
         if (fits32 && pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + ASR_GLDS_BYTES + 4096,
-                                 ctl_words, s))
+                                 ctl_words, err_flag, s))
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
     // one launch per step.  64-row tiles (bt = 2) halve the W_hh re-reads but were
@@ -1111,7 +1112,7 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const voi
                                        const void *gates_bf16, const float *csave,
                                        void *dgates_bf16,
                                        void *workspace, int64_t workspace_bytes,
-                                       void *stream) {
+                                       uint32_t *err_flag, void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0) return ASR_EINVAL;
     if (T == 0) return ASR_OK;
     if (!dy || !whhT_bf16 || !lens || !gates_bf16 || !csave || !dgates_bf16 || !workspace)
@@ -1142,7 +1143,7 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const voi
 #undef ASR_PICK
         const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (1ull << 32);   // 32-bit byte offsets
         if (fits32 && pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 4) * 1024 + ASR_GLDS_BYTES + 16384,
-                                 ctl_words, s))
+                                 ctl_words, err_flag, s))
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
     const int bt = 1;

@@ -84,3 +84,37 @@ def test_pmc_summary_tool(tmp_path, monkeypatch):
     j = json.load(open(out))
     assert j['batch'] == 576
     assert j['kernels']['kern_a(int)'] == {'dispatches': 2, 'fetch_KB': 12.0, 'write_KB': 6.0}
+
+
+def test_step_flops_matches_survey_figures():
+    """LSTM 13.27 MFLOP + conv2 1.10 MFLOP + projection 0.03 MFLOP per encoded
+    frame forward (synthetic shape), conv1 2*32*17*49 per conv1 output frame; training = 3x."""
+    b = load(os.path.join(ROOT, 'bench.py'), 'bench_mod4')
+    B, T, C = 2, 1000, 49
+    per_enc = 13.27e6 + 2 * 32 * 11 * 32 * 49 + 2 * 320 * C
+    want = 3 * B * (334 * per_enc + 1006 * 2 * 32 * 17 * 49)
+    assert abs(b.step_flops(B, T, C) - want) < 2e-3 * want
+
+
+def test_gpus_n_without_rank_environment_launches_the_ranks():
+    """`python bench.py --gpus 2` the way the driver calls it: the process starts two ranks
+    itself (torch.distributed.run child), relays ONE JSON line and the child's exit code.
+    Rehearsed without a GPU (gloo ranks, no model)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3',
+                        '--warmup', '1', '--batch', '4', '--dry-run-launcher'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300,
+                       universal_newlines=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['dry_run'] is True
+    # a world size that disagrees with --gpus is an error exit, not an assert deep inside
+    env2 = dict(env, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run-launcher'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env2, timeout=120,
+                       universal_newlines=True)
+    assert r.returncode != 0 and r.stdout.strip() == ''

@@ -120,3 +120,30 @@ def test_persistent_recurrence_is_bitwise_the_per_step_one(T, B, H, reps):
                 a, b = a[m], b[m]
             assert not torch.isnan(a.float()).any(), name
             assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+
+
+def test_handoff_timeout_surfaces_as_an_error(monkeypatch):
+    """A persistent-recurrence hand-off whose spin bound expires poisons the outputs with
+    NaN and sets the caller's error word; `_native.lstm_check_errors` (called once per step
+    by dp.train_step) must raise instead of letting the NaNs reach the weights.  The
+    timeout is forced with the debug bound ASR_LSTM_SPIN_LIMIT=0; a normal call afterwards
+    is clean again."""
+    from att_speech import _native
+    from att_speech.modules.encoders.native_lstm import bilstm
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    T, B, F, H = 6, 40, 64, 320          # H = 320: five workgroups per team -> real hand-offs
+    rnn = nn.LSTM(F, H, bidirectional=True, bias=False).to(dev)
+    x = torch.randn(T, B, F, device=dev)
+    lens = torch.full((B,), T, dtype=torch.int64)
+    _native.lstm_check_errors()                       # clean before
+    monkeypatch.setenv('ASR_LSTM_SPIN_LIMIT', '0')
+    y = bilstm(x, lens, rnn)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='hand-off timed out'):
+        _native.lstm_check_errors()
+    assert not bool(torch.isfinite(y).all())
+    monkeypatch.delenv('ASR_LSTM_SPIN_LIMIT')
+    y = bilstm(x, lens, rnn)
+    _native.lstm_check_errors()                       # the word was cleared by the raise
+    assert bool(torch.isfinite(y).all())
