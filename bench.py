@@ -158,11 +158,12 @@ def _cpu_loss(model, gg, enc, elens, texts, llens):
     return (num - (mx.squeeze(-1) * mask).sum(0)).sum()
 
 
-def cpu_baseline(T, order, dev=None, seconds_budget=15.0):
+def cpu_baseline(T, order, dev=None, state_dict=None, seconds_budget=15.0):
     """The same training step on the host: torch-CPU encoder/projection +
     oracle/lattice_oracle.c for the lattice (kind 'port'), small batch.  With
     `dev`: also the loss delta of that batch between the product model on the
-    GPU and this fp32 CPU composition (same weights, before any update).
+    GPU and this fp32 CPU composition, both carrying `state_dict` (the weights the
+    timed steps trained: peaked outputs; at random init the loss is insensitive).
     Returns (cpu_baseline dict, loss_delta dict or None)."""
     from att_speech.models import SpeechModel
     from att_speech import fst_utils
@@ -186,6 +187,8 @@ def cpu_baseline(T, order, dev=None, seconds_budget=15.0):
 
     delta = None
     if dev is not None:
+        if state_dict is not None:
+            model.load_state_dict({k: v.detach().float().cpu() for k, v in state_dict.items()})
         gpu_model = copy.deepcopy(model).to(dev)
         with torch.no_grad():
             enc_c, elens = model.encoder(feats, lens, None)
@@ -198,7 +201,7 @@ def cpu_baseline(T, order, dev=None, seconds_budget=15.0):
             'end_to_end_rel': abs(loss_gpu - loss_cpu) / abs(loss_cpu),
             'decoder_lattice_rel': abs(loss_dec_gpu - loss_dec_cpu) / abs(loss_dec_cpu),
             'loss_gpu': loss_gpu, 'loss_cpu': loss_cpu,
-            'batch': '%d x %d frames, same weights; end_to_end = bf16-operand encoder on '
+            'batch': '%d x %d frames, the weights after the timed steps on both sides; end_to_end = bf16-operand encoder on '
                      'the GPU vs fp32 torch-CPU encoder; decoder_lattice = projection + '
                      'log-softmax + lattice on the SAME (GPU) encoder output, fp32 both '
                      'sides (north_star bound 1e-4)' % (B, T)}
@@ -522,7 +525,7 @@ def main():
             res['roofline_bichar'] = bichar_numerator_roofline(dev)
         if world == 1 and not a.no_cpu_baseline and a.workload != 'ctcg_bi_cde':
             progress('loss delta + timing the CPU baseline (about 25 s)')
-            res['cpu_baseline'], res['loss_delta'] = cpu_baseline(T, order, dev)
+            res['cpu_baseline'], res['loss_delta'] = cpu_baseline(T, order, dev, model.state_dict())
         else:
             res['cpu_baseline'] = None
             res['loss_delta'] = None

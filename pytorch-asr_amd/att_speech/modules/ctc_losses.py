@@ -3,9 +3,11 @@
 
 Kept: get_normalized_acts (:29-43), ctc_loss (:46-64, evaluated with the
 lattice kernel instead of F.ctc_loss, same 'mean' reduction), ctc_fst_loss
-(:617-657).  The dense transition-matrix CTC (RawGenericCTC*, :268-390) is not
-used by any shipped YAML and lives only in the golden fixtures as an
-independent oracle."""
+(:617-657), and ctc_raw_loss / ctc_raw_loss_batch (:521-609) as front-ends of the
+same sparse lattice kernel: the reference evaluates those two with dense
+[N, N] transition matrices (RawGenericCTC*, :268-390, O(T N^2)); the value is the
+same sum over alignments, so no dense path is built here — the dense
+arithmetic lives in the golden fixtures as an independent oracle."""
 from __future__ import absolute_import, division, print_function
 
 import numpy as np
@@ -131,3 +133,48 @@ def ctc_loss(acts, labels, act_lens, label_lens,
     losses = torch.where(losses >= 5e19, torch.full_like(losses, float('inf')), losses)
     tl = torch.as_tensor(label_lens).to(losses.device, losses.dtype).clamp(min=1)
     return (losses / tl).mean()
+
+
+def ctc_raw_loss_batch(acts, labels, act_lens, label_lens,
+                       num_symbols=0, context_order=1, normalize_by_dim=None,
+                       allow_nonblank_selfloops=True,
+                       loop_using_symbol_repetitions=False,
+                       eval_repeats_in_context=False,
+                       other_data_in_batch=None,
+                       **kwargs):
+    """reference ctc_losses.py:563-609 — per-utterance CTC losses over the dense
+    mono / bicontext transition matrices (get_CTC_matrices_mono :67-94,
+    get_CTC_matrices_bicontext :111-166).  Same alignments as the sparse training
+    lattice of CTCGraphGen, so it is evaluated with the lattice kernel.  The bicontext
+    matrices with eval_repeats_in_context=False treat a repeated symbol differently
+    from the FST lattice; that combination is refused for label
+    sequences that contain a repeat instead of returning a different number."""
+    assert not other_data_in_batch
+    assert not (eval_repeats_in_context and loop_using_symbol_repetitions)
+    if kwargs:
+        raise NotImplementedError("ctc_raw_loss: unsupported options %s" % sorted(kwargs))
+    if context_order == 1:
+        assert not loop_using_symbol_repetitions
+        return ctc_fst_loss(acts, labels, act_lens, label_lens, num_symbols=num_symbols,
+                            context_order=1, normalize_by_dim=normalize_by_dim)
+    assert context_order == 2 and normalize_by_dim == 1 and num_symbols > 0
+    if loop_using_symbol_repetitions:
+        raise NotImplementedError("loop_using_symbol_repetitions lattices are not built")
+    if not eval_repeats_in_context:
+        flat = torch.as_tensor(labels).long().cpu() % num_symbols
+        ends = torch.as_tensor(label_lens).long().cpu().cumsum(0).tolist()
+        start = 0
+        for end in ends:
+            seq = flat[start:end]
+            if seq.numel() > 1 and bool((seq[1:] == seq[:-1]).any()):
+                raise NotImplementedError(
+                    "dense bicontext CTC with eval_repeats_in_context=False on a label "
+                    "sequence with a repeated symbol differs from the FST lattice")
+            start = end
+    return ctc_fst_loss(acts, labels, act_lens, label_lens, num_symbols=num_symbols,
+                        context_order=2, normalize_by_dim=normalize_by_dim,
+                        allow_nonblank_selfloops=allow_nonblank_selfloops)
+
+
+# the reference's per-utterance Python loop (:521-560) computes the same values
+ctc_raw_loss = ctc_raw_loss_batch

@@ -23,30 +23,28 @@ class Identity(nn.Module):
         return x
 
 
+_NORM_LAYERS = {('batch_norm', 1): nn.BatchNorm1d, ('batch_norm', 2): nn.BatchNorm2d,
+                ('instance_norm', 1): nn.InstanceNorm1d, ('instance_norm', 2): nn.InstanceNorm2d}
+
+
 class Normalization(nn.Module):
+    """`norm_type` in {batch_norm, instance_norm, none / empty} over `nary`-dimensional
+    feature maps; the layer is the attribute `batch_norm` whatever its kind (state_dict
+    prefix `...batch_norm.*`, reference :16-52)."""
+
     def __init__(self, norm_type, nary, input_size):
         super(Normalization, self).__init__()
         self.nary = nary
-        if norm_type == 'batch_norm':
-            if nary == 1:
-                self.batch_norm = nn.BatchNorm1d(input_size)
-            elif nary == 2:
-                self.batch_norm = nn.BatchNorm2d(input_size)
-            else:
-                raise ValueError("Unknown nary for {} normalization".format(norm_type))
-        elif norm_type == 'instance_norm':
-            if nary == 1:
-                self.batch_norm = nn.InstanceNorm1d(input_size)
-            elif nary == 2:
-                self.batch_norm = nn.InstanceNorm2d(input_size)
-            else:
-                raise ValueError("Unknown nary for {} normalization".format(norm_type))
-        elif not norm_type or norm_type == 'none':
+        kind = norm_type or 'none'
+        if kind == 'none':
             self.batch_norm = Identity()
+        elif kind not in ('batch_norm', 'instance_norm'):
+            raise ValueError("Unknown normalization type {}. Possible are: batch_norm, "
+                             "instance_norm or none".format(norm_type))
+        elif (kind, nary) not in _NORM_LAYERS:
+            raise ValueError("Unknown nary for {} normalization".format(norm_type))
         else:
-            raise ValueError(
-                "Unknown normalization type {}. Possible are: batch_norm, "
-                "instance_norm or none".format(norm_type))
+            self.batch_norm = _NORM_LAYERS[kind, nary](input_size)
 
     def forward(self, x, speaker=None):
         return self.batch_norm(x)

@@ -18,44 +18,54 @@ from att_speech.modules.hooks.hook import TrainingLoopHook
 logger = DefaultTensorLogger()
 
 
+class _NormStats(object):
+    """min / mean / max of the unclipped norm and the clip / skip fractions since
+    the last time they were written to the logger."""
+
+    def __init__(self):
+        self.norms, self.clips, self.skips = [], 0, 0
+
+    def add(self, norm, clipped, skipped):
+        self.norms.append(norm)
+        self.clips += clipped
+        self.skips += skipped
+
+    def write(self, log):
+        n = float(len(self.norms))
+        for name, value in (("min", min(self.norms)), ("max", max(self.norms)),
+                            ("mean", sum(self.norms) / n), ("clipfrac", self.clips / n),
+                            ("skipfrac", self.skips / n)):
+            log.log_scalar("gclip/" + name, value)
+
+
 class GradientClipping(TrainingLoopHook):
     def __init__(self, clip_norm, skip_step_norm=np.inf, **kwargs):
-        self.clip_norm = clip_norm
-        self.skip_step_norm = skip_step_norm
+        super(GradientClipping, self).__init__(**kwargs)
+        self.clip_norm, self.skip_step_norm = clip_norm, skip_step_norm
         self.gstats = None
         self.bucket = None          # set by dp.train_step when a flat bucket is in use
-        super(GradientClipping, self).__init__(**kwargs)
 
     def _clip(self, model):
-        b = self.bucket
-        if b is not None:
-            b.check_views()
-            norm = float(b.flat.norm(2))
-            # same rule as clip_grad_norm_: scale by clip/(norm + 1e-6) when that is < 1
-            coef = self.clip_norm / (norm + 1e-6)
-            if coef < 1:
-                b.flat.mul_(coef)
-            return norm
-        return float(clip_grad_norm_(model.get_parameters_for_optimizer(), self.clip_norm))
+        """Scale the gradient to norm <= clip_norm; returns the norm before scaling."""
+        flat = None if self.bucket is None else self.bucket.flat
+        if flat is None:
+            return float(clip_grad_norm_(model.get_parameters_for_optimizer(), self.clip_norm))
+        self.bucket.check_views()
+        norm = float(flat.norm(2))
+        scale = self.clip_norm / (norm + 1e-6)          # clip_grad_norm_'s rule
+        if scale < 1:
+            flat.mul_(scale)
+        return norm
 
     def post_backward(self, model, optimizer, current_iteration, loss):
-        unclipped_norm = self._clip(model)
-        clipped = int(unclipped_norm > self.clip_norm)
-        skipped = int(unclipped_norm > self.skip_step_norm)
+        norm = self._clip(model)
+        too_large, skip = norm > self.clip_norm, norm > self.skip_step_norm
         if self.gstats is None:
-            self.gstats = (1, unclipped_norm, unclipped_norm, unclipped_norm, clipped, skipped)
-        else:
-            n, g_min, g_sum, g_max, n_clip, n_skip = self.gstats
-            self.gstats = (n + 1, min(g_min, unclipped_norm), g_sum + unclipped_norm,
-                           max(g_max, unclipped_norm), n_clip + clipped, n_skip + skipped)
+            self.gstats = _NormStats()
+        self.gstats.add(norm, int(too_large), int(skip))
         if logger.is_currently_logging():
-            n, g_min, g_sum, g_max, n_clip, n_skip = self.gstats
-            logger.log_scalar("gclip/min", g_min)
-            logger.log_scalar("gclip/max", g_max)
-            logger.log_scalar("gclip/mean", 1.0 * g_sum / n)
-            logger.log_scalar("gclip/clipfrac", 1.0 * n_clip / n)
-            logger.log_scalar("gclip/skipfrac", 1.0 * n_skip / n)
+            self.gstats.write(logger)
             self.gstats = None
-        if clipped:
-            print("Grad clipped by ", 1.0 * self.clip_norm / unclipped_norm)
-        return bool(skipped)            # tells the trainer to skip this step
+        if too_large:
+            print("Grad clipped by ", self.clip_norm / norm)
+        return bool(skip)               # truthy: the trainer skips this optimizer step

@@ -6,28 +6,25 @@ import importlib
 
 
 def get_class(str_or_class, default_mod=None):
-    if isinstance(str_or_class, str):
-        parts = str_or_class.split('.')
-        mod_name = '.'.join(parts[:-1])
-        class_name = parts[-1]
-        if mod_name:
-            mod = importlib.import_module(mod_name)
-        elif default_mod is not None:
-            mod = importlib.import_module(default_mod)
-        else:
-            raise ValueError('Specify a module for %s' % (str_or_class,))
-        return getattr(mod, class_name)
-    return str_or_class
+    """`'pkg.module.Name'` -> the object; a bare `'Name'` is looked up in `default_mod`;
+    anything that is not a string is returned as it is."""
+    if not isinstance(str_or_class, str):
+        return str_or_class
+    module_path, _, attribute = str_or_class.rpartition('.')
+    module_path = module_path or default_mod
+    if not module_path:
+        raise ValueError('Specify a module for %s' % (str_or_class,))
+    return getattr(importlib.import_module(module_path), attribute)
 
 
 def contruct_from_kwargs(object_kwargs, default_mod=None,
                          additional_parameters=None):
-    object_kwargs = dict(object_kwargs)
-    class_name = object_kwargs.pop('class_name')
-    klass = get_class(class_name, default_mod)
-    if additional_parameters:
-        object_kwargs.update(additional_parameters)
-    return klass(**object_kwargs)
+    """Instantiate `object_kwargs['class_name']` with the remaining entries as keyword
+    arguments; `additional_parameters` are added last (they win).  The name keeps the
+    reference's spelling because callers import it."""
+    kwargs = {k: v for k, v in dict(object_kwargs).items() if k != 'class_name'}
+    kwargs.update(additional_parameters or {})
+    return get_class(object_kwargs['class_name'], default_mod)(**kwargs)
 
 
 def edit_distance(x, y):

@@ -68,7 +68,7 @@ def _worker(rank, world, port, q):
     hook = GradientClipping(clip_norm=0.5)
     opt = torch.optim.SGD(model.parameters(), lr=0.0)
     train_step(Wrap(model), opt, ((x[idx], lens[idx]), {}), hooks=[hook], bucket=bucket)
-    clip_info = (float(bucket.flat.norm()), hook.gstats[1])
+    clip_info = (float(bucket.flat.norm()), hook.gstats.norms[0])
     # plain numpy through the queue: shared-memory tensors need the sender alive until received
     q.put((rank, idx, grads, clip_info))
     dist.barrier()

@@ -49,8 +49,8 @@ def test_gradient_clipping_matches_clip_grad_norm_and_skips():
             coef = min(1.0, clip / (total + 1e-6))
             for p, t in zip(m.parameters(), g):
                 torch.testing.assert_close(p.grad, t * coef, rtol=1e-5, atol=1e-7)
-            assert hook.gstats[0] == 1 and abs(hook.gstats[1] - total) < 1e-4 * total
-            assert hook.gstats[4] == int(total > clip) and hook.gstats[5] == int(want_skip)
+            assert len(hook.gstats.norms) == 1 and abs(hook.gstats.norms[0] - total) < 1e-4 * total
+            assert hook.gstats.clips == int(total > clip) and hook.gstats.skips == int(want_skip)
 
 
 def test_polyak_decay_is_the_reference_recurrence():
