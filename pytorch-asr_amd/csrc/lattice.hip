@@ -28,9 +28,7 @@ struct FwbwParams {
     int N, Kin, Kout, Bg;
     float neg_inf;
     float *logZ, *grad, *logZ_bwd;
-    float *alphas;  // [T,B,N]
-    int *skip;      // [B] or null: utterances already done by the band kernel
-    int *split;     // [B] (FL == 2): 1 = posteriors left in ws for lattice_scatter_kernel
+    float *alphas;  // workspace, [T+2,B,roundup(N,64)] for the meet-in-the-middle kernels
 };
 
 // KR > 0: every thread owns ONE state (N <= blockDim) and keeps its <= KR
@@ -505,15 +503,27 @@ __global__ __launch_bounds__(1024) void lattice_fwbw_mitm_kernel(FwbwParams p) {
 //   alpha_{t+1}[n] = lp_t[label n] + LSE_k(w_k + alpha_t[src_k])
 //   beta_t[n]      = LSE_k(w_k + (beta_{t+1} + lp_t[label .])[dst_k])
 //   d logZ / d lp_t[c] = sum_{n: label n = c} exp(alpha_{t+1}[n] + beta_{t+1}[n] - logZ)
-// i.e. ONE emission fetch, ONE posterior exp and ONE LDS add per state and
-// frame instead of one per arc.  Same meet-in-the-middle schedule as
-// lattice_fwbw_mitm_kernel.  All scores are kept in log2 units so the
-// recurrences use the raw v_exp_f32 / v_log_f32 (no range-reduction code);
-// results are converted back on output.  The label shared by most lanes of a
-// wave (the blank, label of lane 0's state) is reduced with DPP before the LDS
-// add so it costs one ds_add per wave instead of a 32-way same-address add.
+// i.e. ONE emission fetch and ONE posterior exp per state and frame instead of
+// one per arc.  Same meet-in-the-middle schedule as lattice_fwbw_mitm_kernel.
+// All scores are kept in log2 units so the recurrences use the raw v_exp_f32 /
+// v_log_f32 (no range-reduction code); results are converted back on output.
 //
-// ws[t,b,n] (log2 units): alpha_{t+1}[n] for t < m, beta_{t+1}[n] for t >= m.
+// Per-class posterior sums (FL == 1, C <= H): the recurrence reads its sources
+// through LDS pointers, so the assignment of states to lanes is free.  At kernel
+// entry the states are counting-sorted BY LABEL (position = start of the label's
+// run + rank within it); states of one class then sit in consecutive lanes and
+// d logZ / d lp_t[c] is a SEGMENTED sum over lanes: four masked row_shr steps
+// (1, 2, 4, 8) and two masked row broadcasts (lane 15 -> next row, lane 31 ->
+// rows 2-3) leave a class's total over the wave in the last lane of its run,
+// which stores it to the frame's gradient row in LDS — six VALU operations and
+// one plain ds_write per lane and frame, where a scatter with LDS float adds
+// costs ~4 cycles per ACTIVE lane (~100 states with a non-blank label per frame).
+// Only classes whose run crosses a wave boundary (the blank of a CTC chain, at
+// most one more per boundary) add their per-wave pieces with ds_add_f32.
+// FL == 0 (C > H: bandwidth-bound, the row flush dominates) keeps one
+// unconditional ds_add per lane with the wave's shared label reduced by DPP.
+//
+// ws[t,b,j] (log2 units, j = lane position): alpha_{t+1} for t < m, beta_{t+1} for t >= m.
 // ---------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -536,6 +546,14 @@ __device__ __forceinline__ float dpp_wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// one step of a segmented inclusive scan: v += mask * v[lane picked by the DPP control]
+// (lanes without a source — outside the row, or disabled by ROWS — add 0)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float seg_add(float v, float mask) {
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, true);
+    return fmaf(__builtin_bit_cast(float, y), mask, v);
+}
+
 #ifdef ASR_SL_NOBAR
 #define SL_BARRIER() do {} while (0)
 #else
@@ -549,19 +567,12 @@ __device__ __forceinline__ float dpp_wave_sum(float v) {
 template <int K, int D, int FL>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
 void lattice_fwbw_sl_kernel(FwbwParams p) {
-    // FL == 1: C <= H, the per-step row flush is one store per lane;
-    // FL == 0: runtime flush loop (large C, bandwidth-bound regime);
-    // FL == 2: split scatter — phase 1 leaves the state posteriors gamma_f[n] in the
-    //          workspace (in place of the value it consumed: slot f for f < m, slot f+1
-    //          for f >= m) and lattice_scatter_kernel sums them per class afterwards at
-    //          full occupancy, so nothing but the recurrence sits on the sequential chain.
+    // FL == 1: C <= H: states sorted by label, per-class sums by segmented scan, the
+    //          per-step row flush is one store per lane;
+    // FL == 0: runtime flush loop (large C, bandwidth-bound regime), LDS float adds.
     extern __shared__ float smem[];
     typedef unsigned int u32;
     const int b = blockIdx.x;
-    if (p.skip && p.skip[b]) {                        // done by lattice_fwbw_band_kernel
-        if (FL == 2 && threadIdx.x == 0) p.split[b] = 0;
-        return;
-    }
     const int H = blockDim.x >> 1;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >= (unsigned)H ? 1 : 0);
     const int n = threadIdx.x - grp * H;
@@ -579,22 +590,71 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
     const float *term = p.term + (size_t)g * N;
     const float half_inf = p.neg_inf * 0.5f;
     const float NI2 = p.neg_inf * ASR_L2E;
-    const bool own = n < N;
+    bool own = n < N;
 
-    // ---- state-labelled check -------------------------------------------
+    // ---- state-labelled check (lane n looks at state n) -------------------
     int label = 0;
     bool ok = true;
     if (own) {
         label = il_in[n * Kin];
         for (int k = 1; k < Kin; ++k)
             if (w_in[n * Kin + k] > half_inf && il_in[n * Kin + k] != label) ok = false;
+        if (FL == 1 && (label < 0 || label >= C)) ok = false;
     }
     if (!__syncthreads_and(ok)) {
-        if (FL == 2 && threadIdx.x == 0) p.split[b] = 0;
         lattice_fwbw_mitm_body<4, 8>(p, smem);
         return;
     }
-    if (FL == 2 && threadIdx.x == 0) p.split[b] = 1;
+
+    // ---- FL == 1: counting sort of the states by label ---------------------
+    // lane n then holds the state at POSITION n; sid = its state id.
+    int sid = n;
+    float m1 = 0.f, m2 = 0.f, m4 = 0.f, m8 = 0.f, mb15 = 0.f, mb31 = 0.f;
+    bool seg_plain = false, seg_multi = false;
+    int *const srt = reinterpret_cast<int *>(red + 64 + 2 * H);
+    int *const inv = srt + 2 * Cpad + 2 * H;          // [H] position -> state
+    int *const pos = srt + 2 * Cpad;                  // [H] state -> position
+    if (FL == 1) {
+        int *const cnt = srt, *const cstart = srt + Cpad, *const slab = srt + 2 * Cpad + H;
+        for (int c = threadIdx.x; c < Cpad; c += blockDim.x) cnt[c] = 0;
+        for (int i = threadIdx.x; i < H; i += blockDim.x) slab[i] = 0x7fffffff;
+        __syncthreads();
+        int rank = 0;
+        const int wv = threadIdx.x >> 6;
+        for (int w = 0; w < (H >> 6); ++w) {          // the A group's waves in turn: a fixed order
+            if (wv == w && own) rank = atomicAdd(&cnt[label], 1);
+            __syncthreads();
+        }
+        if (threadIdx.x < (unsigned)C) {              // start of every class's run
+            int acc = 0;
+            for (int c = 0; c < (int)threadIdx.x; ++c) acc += cnt[c];
+            cstart[threadIdx.x] = acc;
+        }
+        __syncthreads();
+        if (grp == 0 && own) {
+            const int pp = cstart[label] + rank;
+            pos[n] = pp;
+            inv[pp] = n;
+            slab[pp] = label;
+        }
+        __syncthreads();
+        // take over position n (positions 0..N-1 are exactly the N states)
+        sid = own ? inv[n] : 0;
+        const int sl = slab[n];                       // 0x7fffffff on empty positions
+        label = own ? sl : 0;
+        const int l = n & 63, wb = n & ~63, r16 = l >> 4;
+        auto same = [&](int j) -> float { return (own && slab[j] == sl) ? 1.f : 0.f; };
+        m1 = (l & 15) >= 1 ? same(n - 1) : 0.f;
+        m2 = (l & 15) >= 2 ? same(n - 2) : 0.f;
+        m4 = (l & 15) >= 4 ? same(n - 4) : 0.f;
+        m8 = (l & 15) >= 8 ? same(n - 8) : 0.f;
+        mb15 = (r16 & 1) ? same(wb + 16 * r16 - 1) : 0.f;
+        mb31 = r16 >= 2 ? same(wb + 31) : 0.f;
+        const bool seg_end = own && (l == 63 || slab[n + 1] != sl);
+        const bool multi = own && (cstart[label] >> 6) != ((cstart[label] + cnt[label] - 1) >> 6);
+        seg_plain = seg_end && !multi;
+        seg_multi = seg_end && multi;
+    }
 
     int len = p.lens[b];
     len = len < 0 ? 0 : (len > p.T ? p.T : len);
@@ -604,10 +664,9 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
     const size_t tstride = (size_t)p.B * C;
     float *grad_b = p.grad + (size_t)b * C;
 
-    if (FL != 2)
-        for (int t = len; t < p.T; ++t)              // fst_utils.py:448
-            for (int c = threadIdx.x; c < C; c += blockDim.x)
-                grad_b[(size_t)t * tstride + c] = 0.f;
+    for (int t = len; t < p.T; ++t)                  // fst_utils.py:448
+        for (int c = threadIdx.x; c < C; c += blockDim.x)
+            grad_b[(size_t)t * tstride + c] = 0.f;
 
     // ---- buffer resources: every global access of the scan goes through a
     // bounds-checked raw buffer with a per-lane 32-bit byte offset, so the
@@ -654,13 +713,14 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const bool v = own && k < Kg;
-            s0[k] = sbuf + (v ? oth[n * Kg + k] : 0);
-            const float w = v ? wp[n * Kg + k] : p.neg_inf;
+            const int o = v ? oth[sid * Kg + k] : 0;
+            s0[k] = sbuf + (FL == 1 ? (v ? pos[o] : 0) : o);
+            const float w = v ? wp[sid * Kg + k] : p.neg_inf;
             r_w[k] = w > half_inf ? w * ASR_L2E : NI2;
         }
     }
     float *const mine = sbuf + n;
-    const float term2 = own ? fmaxf(term[n], p.neg_inf) * ASR_L2E : NI2;
+    const float term2 = own ? fmaxf(term[sid], p.neg_inf) * ASR_L2E : NI2;
     float breg = term2;                               // B: beta_{t+1}[n] (log2)
     float logZ2 = 0.f;
     const int lane = threadIdx.x & 63;
@@ -696,23 +756,31 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
     int ra = 0, rf = Cpad, rn = 2 * Cpad;
     float gprev = 0.f;                // posterior of the previous step, not yet added
 
-    // side work of phase-1 step i: add gprev into row ra, flush row rf
+    // side work of phase-1 step i: sum gprev per class into row ra, flush row rf
     // (frame of step i-2, offset gcur, masked off while i < 2), rotate.
-    // ONE unconditional ds_add per lane (exact LDS op count keeps the
-    // compiler's lgkmcnt waits counted): lane 0 adds the DPP-reduced total of
-    // the wave's shared label, lanes with another label add their own
-    // posterior, everything else (zeros) goes to a lane-private sink.
-    // (LDS float adds cost ~4 cycles per ACTIVE lane on gfx950: for small C
-    // only lanes with a non-zero, non-shared posterior issue one; for large C
-    // the single unconditional form is faster — measured 878 -> 783 us on the
-    // bigram numerator — because it keeps the lgkmcnt waits counted.)
+    // FL == 1: segmented sum over the label-sorted lanes; the last lane of a run
+    // stores the class total (one unconditional plain ds_write per lane, everything
+    // else goes to a lane-private sink: an exact LDS op count keeps the compiler's
+    // lgkmcnt waits counted); runs that cross a wave boundary add their pieces.
+    // FL == 0: ONE unconditional ds_add per lane: lane 0 adds the DPP-reduced total
+    // of the wave's shared label, lanes with another label add their own posterior,
+    // zeros go to the sink (LDS float adds cost ~4 cycles per ACTIVE lane on gfx950;
+    // the unconditional form was measured faster on the bigram numerator, 878 -> 783 us,
+    // because it keeps the lgkmcnt waits counted).
     auto side_accumulate = [&]() {
-        const float tot = dpp_wave_sum(shared_label ? gprev : 0.f);
         if (FL == 1) {
-            float *rw = row + ra;
-            if (lane == 0 && tot != 0.f) atomicAdd(&rw[l0], tot);
-            if (!shared_label && gprev != 0.f) atomicAdd(&rw[label], gprev);
+            float v = gprev;
+            v = seg_add<0x111, 0xF>(v, m1);           // row_shr:1
+            v = seg_add<0x112, 0xF>(v, m2);           // row_shr:2
+            v = seg_add<0x114, 0xF>(v, m4);           // row_shr:4
+            v = seg_add<0x118, 0xF>(v, m8);           // row_shr:8
+            v = seg_add<0x142, 0xA>(v, mb15);         // row_bcast:15 -> rows 1, 3
+            v = seg_add<0x143, 0xC>(v, mb31);         // row_bcast:31 -> rows 2, 3
+            float *rw = row + ra + label;
+            *(seg_plain ? rw : ldump) = v;
+            if (seg_multi) atomicAdd(rw, v);
         } else {
+            const float tot = dpp_wave_sum(shared_label ? gprev : 0.f);
             const float v = lane == 0 ? tot : (shared_label ? 0.f : gprev);
             float *dst = v != 0.f ? row + ra + label : ldump;
             atomicAdd(dst, v);
@@ -737,7 +805,7 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
         float fl = 0.f;
         const int ci = n < C ? n : 0;
         if (PH == 1 && FL == 1) fl = row[rf + ci];
-        if (PH == 1 && FL != 2) {
+        if (PH == 1) {
             // keep the LDS reads ahead of the DPP reduction: it runs in their shadow
             __builtin_amdgcn_sched_barrier(0);
             side_accumulate();
@@ -768,9 +836,7 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
             float gam = __builtin_amdgcn_exp2f((isB ? breg : val1) + wv - logZ2);
             if (!own || !act) gam = 0.f;
             gprev = gam;
-            if (FL == 2) {
-                st(wsR, (SOLO == 0 || act) ? gcur : OOB, gam);
-            } else if (FL == 1) {
+            if (FL == 1) {
             } else if (do_flush) {
                 for (int c = n; c < C; c += H) {
                     st(gradR, gcur + (u32)(c - n) * 4u, row[rf + c]);
@@ -784,7 +850,6 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
     };
     // phase-1 drain step: side work only
     auto drain = [&](bool do_flush) {
-        if (FL == 2) return;
         const int ci = n < C ? n : 0;
         side_accumulate();
         gprev = 0.f;
@@ -814,7 +879,7 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
     {
         const float e_last = ld(lpR, eoff(len - 1));          // OOB -> 0 when len == 0
         mine[0] = isB ? (own ? fmaf(e_last, ASR_L2E, term2) : NI2)   // beta_len + lp_{len-1}
-                      : ((n == 0) ? 0.f : NI2);                      // alpha_0
+                      : ((own && sid == 0) ? 0.f : NI2);             // alpha_0
         st(wsR, isB ? woff(len) : OOB, term2);                // slot len = beta_len
     }
     for (int c = n; c < 3 * Cpad; c += H) row[c] = 0.f;
@@ -891,9 +956,8 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
 
     SL_STAMP(2);
     // ================= phase 1 ============================================
-    // FL == 2: gcur walks the workspace slots this group loads (gamma goes back in place)
-    const u32 gstep = FL == 2 ? wstep : estep;
-    gcur = FL == 2 ? woff(sL1) : n4 + (u32)fG1 * ts4;   // FL != 2: row flushed at step 0 (masked off)
+    const u32 gstep = estep;
+    gcur = n4 + (u32)fG1 * ts4;                   // row flushed at step 0 (masked off)
 #pragma unroll
     for (int u = 0; u < D; ++u)
         if (u < r) {
@@ -935,18 +999,20 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
     }
     {   // logZ = logsumexp_n(alpha_len + terminal) (fst_utils.py:445)
         const float *al = smem + (solo ? H : 0);
+        auto at = [&](int i) -> float {           // alpha_len + terminal of the state at position i
+            return al[i] + fmaxf(term[FL == 1 ? inv[i] : i], p.neg_inf) * ASR_L2E;
+        };
         float mx = -INFINITY;
-        for (int i = threadIdx.x; i < N; i += blockDim.x)
-            mx = fmaxf(mx, al[i] + fmaxf(term[i], p.neg_inf) * ASR_L2E);
+        for (int i = threadIdx.x; i < N; i += blockDim.x) mx = fmaxf(mx, at(i));
         mx = block_max(mx, red);
         float sum = 0.f;
         for (int i = threadIdx.x; i < N; i += blockDim.x)
-            sum += __builtin_amdgcn_exp2f(al[i] + fmaxf(term[i], p.neg_inf) * ASR_L2E - mx);
+            sum += __builtin_amdgcn_exp2f(at(i) - mx);
         sum = block_sum(sum, red);
         if (threadIdx.x == 0) p.logZ[b] = (mx + __builtin_amdgcn_logf(sum)) * ASR_LN2;
     }
     // fst_utils.py:476: logsumexp(alpha_0 + beta_0) == beta_0[0]
-    if (p.logZ_bwd && isB && n == 0) p.logZ_bwd[b] = breg * ASR_LN2;
+    if (p.logZ_bwd && isB && own && sid == 0) p.logZ_bwd[b] = breg * ASR_LN2;
 #ifdef ASR_SL_STAMPS
     SL_STAMP(4);
     __syncthreads();
@@ -955,71 +1021,6 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
         for (int i = 0; i < 4; ++i) o[i] = (float)(stamp[i + 1] - stamp[i]);
     }
 #endif
-}
-
-// ---------------------------------------------------------------------------
-// Second half of the split scatter (lattice_fwbw_sl_kernel<.., 2>): per frame and
-// utterance, grad[f,b,c] = sum_{n: label n = c} gamma_f[n] with gamma read from the
-// workspace (slot f for f < len/2, slot f+1 above), zeros for f >= len
-// (fst_utils.py:448).  One 4-wave workgroup per utterance and chunk of 4*FPW
-// frames; a wave takes one frame per iteration: H/64 coalesced loads per lane,
-// the label of state 0 (the blank of a CTC chain, shared by half the states) is
-// summed with DPP, the others with LDS float adds into the wave's own bins.
-// ---------------------------------------------------------------------------
-template <int NJ, int FPW>
-__global__ __launch_bounds__(256) void lattice_scatter_kernel(FwbwParams p) {
-    extern __shared__ float smem[];
-    const int b = blockIdx.x;
-    if (!p.split[b]) return;
-    const int N = p.N, C = p.C, H = NJ * 64;
-    const int Cpad = (C + 3) & ~3;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *bins = smem + wave * Cpad;
-    const int g = (p.Bg == 1) ? 0 : b;
-    const int32_t *il_in = p.il_in + (size_t)g * N * p.Kin;
-    int lab[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = lane + 64 * j;
-        lab[j] = n < N ? il_in[(size_t)n * p.Kin] : -1;
-    }
-    const int l0 = __builtin_amdgcn_readfirstlane(lab[0]);
-    int len = p.lens[b];
-    len = len < 0 ? 0 : (len > p.T ? p.T : len);
-    const int m = len >> 1;
-    for (int c = lane; c < Cpad; c += 64) bins[c] = 0.f;
-    const int f0 = blockIdx.y * (4 * FPW) + wave;
-    float v[FPW][NJ];
-#pragma unroll
-    for (int it = 0; it < FPW; ++it) {
-        const int f = f0 + 4 * it;
-        const int slot = f < m ? f : f + 1;
-        const float *src = p.alphas + ((size_t)slot * p.B + b) * H;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            v[it][j] = (f < len && lab[j] >= 0) ? src[lane + 64 * j] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < FPW; ++it) {
-        const int f = f0 + 4 * it;
-        float t0 = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const bool sh = lab[j] == l0;
-            t0 += sh ? v[it][j] : 0.f;
-            if (!sh && v[it][j] != 0.f) atomicAdd(&bins[lab[j]], v[it][j]);
-        }
-        const float tot = dpp_wave_sum(t0);
-        __syncthreads();
-        float *dst = p.grad + ((size_t)f * p.B + b) * C;
-        for (int c = lane; c < C; c += 64) {
-            const float x = bins[c] + (c == l0 ? tot : 0.f);
-            bins[c] = 0.f;
-            if (f < p.T) dst[c] = x;
-        }
-        __syncthreads();
-    }
 }
 
 struct FwdParams {
@@ -1034,399 +1035,6 @@ struct FwdParams {
     int32_t *best_il;
     uint16_t *bp;  // [T,B,N] arg-max arc slot, viterbi only
 };
-
-// ---------------------------------------------------------------------------
-// BAND lattices: state-labelled graphs whose in-arcs come from states
-// {n, n-1, n-2} and whose out-arcs go to {n, n+1, n+2} — every CTC numerator
-// lattice of the reference (compose(decoding_fst, chain), fst_utils.py:603-613:
-// blank_0, label_0, blank_1, ... with self loops, next-state arcs and the
-// skip-the-blank arc).  For these the scan needs no LDS exchange at all:
-//   * ONE wave per chain: wave 0 runs alpha, wave 1 runs beta (meet in the
-//     middle as above); a lane keeps S consecutive states in registers and gets
-//     the two neighbouring states of the next/previous lane with DPP wave
-//     shifts, so there is no barrier and no LDS round trip on the recurrence;
-//   * the log-prob row of a frame is loaded ONCE per chain (lane c holds class
-//     c, C <= 64) D frames ahead and the per-state emissions are gathered from
-//     it with ds_bpermute;
-//   * posteriors are summed per class without atomics: the slots whose states
-//     all carry one label (the blanks) are reduced with one DPP sum, every
-//     other class sums its <= 16 states through a gather list built once per
-//     utterance.
-// The two waves only meet at the phase boundary (alpha_m / beta_m exchange ->
-// logZ).  Graphs that are not bands (or N > 64*S, C > 64, a class with more
-// than 16 states) leave skip[b] = 0 and are handled by the kernels above.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float wave_shr1(float v, float fill) {     // lane i <- lane i-1
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-        __builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float wave_shl1(float v, float fill) {     // lane i <- lane i+1
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-        __builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
-}
-// log2(2^x0 + 2^x1 + 2^x2): the largest term contributes exactly 1, so two
-// v_exp_f32 (quarter rate) instead of three, for three full-rate min/med/max
-__device__ __forceinline__ float lse3_2(float x0, float x1, float x2) {
-    const float m = __builtin_fmaxf(__builtin_fmaxf(x0, x1), x2);
-    const float lo = __builtin_fminf(__builtin_fminf(x0, x1), x2);
-    const float mid = __builtin_amdgcn_fmed3f(x0, x1, x2);
-    const float s = 1.f + __builtin_amdgcn_exp2f(mid - m) + __builtin_amdgcn_exp2f(lo - m);
-    return m + __builtin_amdgcn_logf(s);
-}
-
-#define BAND_LIST 16
-
-template <int S, int D>
-__global__ __launch_bounds__(128) void lattice_fwbw_band_kernel(FwbwParams p) {
-    typedef unsigned int u32;
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    static_assert(S == 4, "ws rows are moved as one 16-byte access per lane");
-    __shared__ float xch[2][64 * S];                   // alpha_m | beta_m
-    __shared__ __attribute__((aligned(16))) float gbuf[2][64 * S + 4];   // posteriors per chain, [64*S] stays 0
-    __shared__ int labtab[64 * S];
-    __shared__ unsigned short lists[64][2][BAND_LIST];
-    __shared__ int lcnt[64][2];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const bool isB = __builtin_amdgcn_readfirstlane(tid >> 6) != 0;
-    const int N = p.N, C = p.C;
-    const int g = (p.Bg == 1) ? 0 : b;
-    const int Kin = p.Kin, Kout = p.Kout;
-    const int32_t *src_in = p.src_in + (size_t)g * N * Kin;
-    const int32_t *il_in = p.il_in + (size_t)g * N * Kin;
-    const float *w_in = p.w_in + (size_t)g * N * Kin;
-    const int32_t *dst_out = p.dst_out + (size_t)g * N * Kout;
-    const float *w_out = p.w_out + (size_t)g * N * Kout;
-    const float *term = p.term + (size_t)g * N;
-    const float half_inf = p.neg_inf * 0.5f;
-    const float NI2 = p.neg_inf * ASR_L2E;
-
-    // ---- per-lane states n = S*lane + s: band weights, labels, structure check
-    int lab[S];
-    float wb[S][3], term2[S];
-    bool dead[S];
-    bool ok = true;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int n = lane * S + s;
-        const bool valid = n < N;
-        lab[s] = valid ? il_in[(size_t)n * Kin] : 0;
-        if (valid && (lab[s] < 0 || lab[s] >= C)) ok = false;
-        float wi0 = NI2, wi1 = NI2, wi2 = NI2, wo0 = NI2, wo1 = NI2, wo2 = NI2;
-        if (valid) {
-            for (int k = 0; k < Kin; ++k) {
-                const float w = w_in[(size_t)n * Kin + k];
-                if (w > half_inf) {
-                    const int d = n - src_in[(size_t)n * Kin + k];
-                    const float w2 = w * ASR_L2E;
-                    if (il_in[(size_t)n * Kin + k] != lab[s]) ok = false;
-                    if (d == 0 && wi0 == NI2) wi0 = w2;
-                    else if (d == 1 && wi1 == NI2) wi1 = w2;
-                    else if (d == 2 && wi2 == NI2) wi2 = w2;
-                    else ok = false;
-                }
-            }
-            for (int k = 0; k < Kout; ++k) {
-                const float w = w_out[(size_t)n * Kout + k];
-                if (w > half_inf) {
-                    const int d = dst_out[(size_t)n * Kout + k] - n;
-                    const float w2 = w * ASR_L2E;
-                    if (d == 0 && wo0 == NI2) wo0 = w2;
-                    else if (d == 1 && wo1 == NI2) wo1 = w2;
-                    else if (d == 2 && wo2 == NI2) wo2 = w2;
-                    else ok = false;
-                }
-            }
-        }
-        wb[s][0] = isB ? wo0 : wi0; wb[s][1] = isB ? wo1 : wi1; wb[s][2] = isB ? wo2 : wi2;
-        term2[s] = valid ? fmaxf(term[n], p.neg_inf) * ASR_L2E : NI2;
-        // batch padding / unreachable states (no in-arc, not the start state) never carry mass
-        const bool alive = valid && (n == 0 || wi0 != NI2 || wi1 != NI2 || wi2 != NI2);
-        dead[s] = !alive;
-        labtab[n] = alive ? lab[s] : -1;
-    }
-    // slots whose valid states all share one label are reduced with DPP
-    bool uni[S];
-    int ul[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        ul[s] = __builtin_amdgcn_readfirstlane(lab[s]);
-        const bool same = dead[s] || lab[s] == ul[s];
-        uni[s] = __builtin_amdgcn_read_exec() == __ballot(same);      // wave-uniform
-    }
-    // the uniform slots must share ONE label (the blank); its posterior is one DPP sum per frame
-    int ulab = -1;
-#pragma unroll
-    for (int s = S - 1; s >= 0; --s)
-        if (uni[s]) ulab = ul[s];
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-        if (uni[s] && ul[s] != ulab) ok = false;
-    __syncthreads();
-    // per-class gather lists over the remaining states: thread (class, half) scans half the states
-    {
-        const int c = lane, half = isB ? 1 : 0;
-        const int nb = half ? (N + 1) / 2 : 0, ne = half ? N : (N + 1) / 2;
-        int cnt = 0;
-        for (int n = nb; n < ne; ++n) {
-            const bool u = uni[0] ? (n % S) == 0 : false;
-            bool slot_uni = u;
-#pragma unroll
-            for (int q = 1; q < S; ++q) slot_uni = slot_uni || (uni[q] && (n % S) == q);
-            if (!slot_uni && labtab[n] == c) {
-                if (cnt < BAND_LIST) lists[c][half][cnt] = (unsigned short)n;
-                ++cnt;
-            }
-        }
-        lcnt[c][half] = cnt;
-    }
-    __syncthreads();
-    int mycnt = lcnt[lane][0] + lcnt[lane][1];
-    if (lane >= C) mycnt = 0;
-    if (mycnt > BAND_LIST) ok = false;
-    if (!__syncthreads_and(ok)) {
-        if (tid == 0) p.skip[b] = 0;
-        return;
-    }
-    if (tid == 0) p.skip[b] = 1;
-    int maxcnt = mycnt;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o, 64));
-    maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
-    for (int i = tid; i < 2 * (64 * S + 4); i += 128) (&gbuf[0][0])[i] = 0.f;
-
-    int len = p.lens[b];
-    len = len < 0 ? 0 : (len > p.T ? p.T : len);
-    const size_t tstride = (size_t)p.B * C;
-    float *grad_b = p.grad + (size_t)b * C;
-    for (int t = len; t < p.T; ++t)                  // fst_utils.py:448
-        for (int c = tid; c < C; c += 128) grad_b[(size_t)t * tstride + c] = 0.f;
-
-    // The scan proper, instantiated per chain (ISB) and gather-list length (LN)
-    // so that the loop bodies are single basic blocks with an exact VMEM count
-    // per step (counted vmcnt waits, prefetch distance D steps).
-    auto run = [&](auto isb_c, auto ln_c) {
-        constexpr bool ISB = decltype(isb_c)::value;
-        constexpr int LN = decltype(ln_c)::value;
-        float *const G = gbuf[ISB ? 1 : 0];
-        u32 lidx[LN];             // byte offsets into G; unused entries point at the zero slot
-        {
-            const int c0 = lcnt[lane][0];
-#pragma unroll
-            for (int i = 0; i < LN; ++i) {
-                int n = 64 * S;
-                if (i < mycnt) n = i < c0 ? lists[lane][0][i] : lists[lane][1][i - c0];
-                lidx[i] = (u32)n * 4u;
-            }
-        }
-        const int m = len >> 1, solo = len - 2 * m;
-        // ---- buffers (bounds-checked: masked lanes / steps carry an out-of-range offset)
-        const int Hw = (N + 63) / 64 * 64;           // ws row stride (asr_lattice_fwbw_workspace_bytes)
-        const u32 ts4 = (u32)tstride * 4u, as4 = (u32)p.B * (u32)Hw * 4u;
-        const u32 lp_bytes = (u32)(((size_t)p.T * p.B * C - (size_t)b * C) * 4);
-        const u32 ws_bytes = (u32)(((size_t)(p.T + 2) * p.B * Hw - (size_t)b * Hw) * 4);
-        const __amdgpu_buffer_rsrc_t lpR = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(p.lp) + (size_t)b * C, 0, lp_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t gradR =
-            __builtin_amdgcn_make_buffer_rsrc(grad_b, 0, lp_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t wsR = __builtin_amdgcn_make_buffer_rsrc(
-            p.alphas + (size_t)b * Hw, 0, ws_bytes, 0x00020000);
-        const u32 OOB = 0x80000000u;                 // every buffer is < 2^31 bytes (host check)
-        const u32 c4 = lane < C ? (u32)lane * 4u : OOB;            // this lane's class column
-        const u32 wn4 = lane * S < N ? (u32)lane * S * 4u : OOB;   // this lane's ws columns
-
-        // ---- schedule of this chain: n0 steps before the meeting point, n1 after;
-        // step j works on frame f(j) = j (alpha) or len-1-j (beta).  The first
-        // phase is padded at the front, the second at the back, to whole rings.
-        const int n0 = ISB ? m + solo : m, n1 = ISB ? m : m + solo;
-        const int pad0 = (D - n0 % D) % D;
-        auto frame_of = [&](int j) -> int { return ISB ? len - 1 - j : j; };
-        auto row_off = [&](int j) -> u32 {            // lp row of step j
-            const bool in = (j >= 0) & (j < n0 + n1);
-            return in ? c4 + (u32)frame_of(j) * ts4 : OOB;
-        };
-        float R[D];                                   // ring of log-prob rows (raw)
-#pragma unroll
-        for (int u = 0; u < D; ++u)
-            R[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lpR, row_off(u - pad0), 0, 0));
-        auto gather = [&](float rowv, float (&em)[S]) {
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-                em[s] = ASR_L2E * __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
-                            lab[s] * 4, __builtin_bit_cast(int, rowv)));
-        };
-
-        float a[S];                                   // alpha_t / beta_{t+1}, log2 units
-#pragma unroll
-        for (int s = 0; s < S; ++s) a[s] = ISB ? term2[s] : ((lane == 0 && s == 0) ? 0.f : NI2);
-
-        // one recurrence step with the emissions em of the step's frame
-        auto advance = [&](const float (&em)[S], float (&out)[S]) {
-            if constexpr (!ISB) {
-                const float p3 = wave_shr1(a[S - 1], NI2), p2 = wave_shr1(a[S - 2], NI2);
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float x0 = a[s] + wb[s][0];
-                    const float x1 = (s >= 1 ? a[s >= 1 ? s - 1 : 0] : p3) + wb[s][1];
-                    const float x2 = (s >= 2 ? a[s >= 2 ? s - 2 : 0] : (s == 1 ? p3 : p2)) + wb[s][2];
-                    out[s] = em[s] + lse3_2(x0, x1, x2);
-                }
-            } else {
-                float bt[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) bt[s] = a[s] + em[s];
-                const float q0 = wave_shl1(bt[0], NI2), q1 = wave_shl1(bt[1], NI2);
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float y0 = bt[s] + wb[s][0];
-                    const float y1 = (s + 1 < S ? bt[s + 1 < S ? s + 1 : 0] : q0) + wb[s][1];
-                    const float y2 = (s + 2 < S ? bt[s + 2 < S ? s + 2 : 0] : (s + 2 == S ? q0 : q1)) + wb[s][2];
-                    out[s] = lse3_2(y0, y1, y2);
-                }
-            }
-        };
-
-        float em[S];
-        gather(R[0], em);
-        // ================= phase 0: up to the meeting point, keep the states in ws
-        // alpha: slot t <- alpha_{t+1} after frame t;  beta: slot t <- beta_{t+1} before frame t
-        for (int J0 = 0; J0 < n0 + pad0; J0 += D) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {
-                const int j = J0 + u - pad0;
-                const bool act = j >= 0;
-                float nx[S];
-                advance(em, nx);
-                const u32x4 keep = {__builtin_bit_cast(u32, a[0]), __builtin_bit_cast(u32, a[1]),
-                                    __builtin_bit_cast(u32, a[2]), __builtin_bit_cast(u32, a[3])};
-#pragma unroll
-                for (int s = 0; s < S; ++s) a[s] = act ? nx[s] : a[s];
-                const u32x4 fresh = {__builtin_bit_cast(u32, a[0]), __builtin_bit_cast(u32, a[1]),
-                                     __builtin_bit_cast(u32, a[2]), __builtin_bit_cast(u32, a[3])};
-                const u32 slot = (u32)frame_of(j);
-                __builtin_amdgcn_raw_buffer_store_b128(ISB ? keep : fresh, wsR,
-                                                       act ? wn4 + slot * as4 : OOB, 0, 0);
-                R[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                           lpR, row_off(j + D), 0, 0));
-                __builtin_amdgcn_sched_barrier(0);     // keep the refills D steps ahead of their use
-                gather(R[(u + 1) % D], em);
-            }
-        }
-        // ================= meeting point: logZ = LSE_n(alpha_m + beta_m)
-#pragma unroll
-        for (int s = 0; s < S; ++s) xch[ISB ? 1 : 0][lane * S + s] = a[s];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ws rows of this chain are out
-        __syncthreads();
-        float logZ2;
-        {
-            float v[S], mx = -INFINITY;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                v[s] = xch[0][lane * S + s] + xch[1][lane * S + s];
-                if (lane * S + s >= N) v[s] = -INFINITY;
-                mx = fmaxf(mx, v[s]);
-            }
-            mx = wave_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int s = 0; s < S; ++s) sum += __builtin_amdgcn_exp2f(v[s] - mx);
-            sum = wave_sum(sum);
-            logZ2 = mx + __builtin_amdgcn_logf(sum);
-        }
-        // ================= phase 1: finish the chain; posteriors against the other
-        // chain's stored states (slot t holds alpha_{t+1} for t < m, beta_{t+1} for t >= m)
-        auto ws_off = [&](int k) -> u32 {             // slot read by phase-1 step k
-            return k < n1 ? wn4 + (u32)frame_of(n0 + k) * as4 : OOB;
-        };
-        u32x4 W[D];
-#pragma unroll
-        for (int u = 0; u < D; ++u) W[u] = __builtin_amdgcn_raw_buffer_load_b128(wsR, ws_off(u), 0, 0);
-        float pend[LN];                               // gathered posteriors of the previous step
-        float ptot = 0.f;
-        u32 pgoff = OOB;
-#pragma unroll
-        for (int i = 0; i < LN; ++i) pend[i] = 0.f;
-        auto flush = [&]() {                          // grad row of the previous step
-            float r = lane == ulab ? ptot : 0.f;
-#pragma unroll
-            for (int i = 0; i < LN; ++i) r += pend[i];
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), gradR, pgoff, 0, 0);
-        };
-        for (int K0 = 0; K0 < n1; K0 += D) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {
-                const int k = K0 + u;
-                const bool act = k < n1;
-                float nx[S], gam[S];
-                // (bit_cast of the whole vector: __builtin_bit_cast(float, W[u].y) on a vector ELEMENT
-                // reads the vector's first dword with this hipcc)
-                typedef __attribute__((ext_vector_type(4))) float f32x4v;
-                const f32x4v wf = __builtin_bit_cast(f32x4v, W[u]);
-                const float oth[S] = {wf.x, wf.y, wf.z, wf.w};
-                advance(em, nx);
-                // alpha wave: gamma from the NEW alpha_{t+1}; beta wave: from beta_{t+1} before the update
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float mine = ISB ? a[s] : nx[s];
-                    gam[s] = __builtin_amdgcn_exp2f(mine + oth[s] - logZ2);
-                    const bool live = (lane * S + s < N) & act;
-                    gam[s] = live ? gam[s] : 0.f;
-                    a[s] = act ? nx[s] : a[s];
-                }
-                flush();                               // previous step's row (its LDS reads are long back)
-                // stage this step's posteriors: uniform slots -> one DPP sum, the rest -> gather lists
-                // (scalar stores: a float4-typed store and the float-typed gather loads below would
-                // be "no alias" for the compiler and the store gets dropped)
-#pragma unroll
-                for (int s = 0; s < S; ++s) G[lane * S + s] = gam[s];
-#pragma unroll
-                for (int i = 0; i < LN; ++i)
-                    pend[i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(G) + lidx[i]);
-                {
-                    float v = 0.f;
-#pragma unroll
-                    for (int q = 0; q < S; ++q) v += uni[q] ? gam[q] : 0.f;
-                    ptot = dpp_wave_sum(v);
-                }
-                pgoff = act ? c4 + (u32)frame_of(n0 + k) * ts4 : OOB;
-                W[u] = __builtin_amdgcn_raw_buffer_load_b128(wsR, ws_off(k + D), 0, 0);
-                R[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                           lpR, row_off(n0 + k + D), 0, 0));
-                __builtin_amdgcn_sched_barrier(0);
-                gather(R[(u + 1) % D], em);
-            }
-        }
-        flush();
-        // ================= totals
-        {
-            // alpha: logZ = LSE_n(alpha_len + terminal) (fst_utils.py:445); beta: from beta_0 (:476)
-            float mx = -INFINITY, v[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const float add = ISB ? ((lane == 0 && s == 0) ? 0.f : NI2) : term2[s];
-                v[s] = lane * S + s < N ? a[s] + add : -INFINITY;
-                mx = fmaxf(mx, v[s]);
-            }
-            mx = wave_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int s = 0; s < S; ++s) sum += __builtin_amdgcn_exp2f(v[s] - mx);
-            sum = wave_sum(sum);
-            float *dst = ISB ? p.logZ_bwd : p.logZ;
-            if (lane == 0 && dst) dst[b] = (mx + __builtin_amdgcn_logf(sum)) * ASR_LN2;
-        }
-    };
-    typedef std::integral_constant<bool, false> CA;
-    typedef std::integral_constant<bool, true> CB;
-    typedef std::integral_constant<int, BAND_LIST / 2> L8;
-    typedef std::integral_constant<int, BAND_LIST> L16;
-    if (isB) {
-        if (maxcnt <= BAND_LIST / 2) run(CB(), L8()); else run(CB(), L16());
-    } else {
-        if (maxcnt <= BAND_LIST / 2) run(CA(), L8()); else run(CA(), L16());
-    }
-}
-
-
 
 template <bool VITERBI>
 __global__ void lattice_forward_kernel(FwdParams p) {
@@ -1543,8 +1151,7 @@ extern "C" int64_t asr_lattice_fwbw_workspace_bytes(int T, int B, int C, int N) 
     if (T < 0 || B < 0 || N < 0) return -1;
     // [T+2, B, round_up(N,64)] f32 (+1 slot: beta_len, +1: spare)
     const int64_t H = (N + 63) / 64 * 64;
-    // + [B] band-kernel flags + [B] split-scatter flags
-    return (int64_t)(T + 2) * B * H * (int64_t)sizeof(float) + (int64_t)B * 8 + 256;
+    return (int64_t)(T + 2) * B * H * (int64_t)sizeof(float) + 256;
 }
 
 extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
@@ -1577,9 +1184,6 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     p.N = N; p.Kin = Kin; p.Kout = Kout; p.Bg = Bg; p.neg_inf = neg_inf;
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
-    p.skip = nullptr;
-    p.split = nullptr;
-    bool split_scatter = false;
 
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
@@ -1594,31 +1198,14 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
         // state-labelled fast path; a workgroup whose graph fails the entry
         // check runs the generic body inside the same launch
         const int H = round_up(N, 64);
-        const size_t lds_sl = (size_t)(4 * H + 6 * Cpad + 64 + 2 * H) * sizeof(float);
-        // Experimental (ASR_LATTICE_SPLIT_SCATTER=1): the per-class posterior sums leave
-        // the sequential chain (FL == 2 + lattice_scatter_kernel).  Correct (same tests)
-        // but slower today: 114 + 60 us vs 149 us fused on the B=512 mono numerator.
-        const char *split_env = getenv("ASR_LATTICE_SPLIT_SCATTER");
-        split_scatter = C <= H && T > 0 && split_env && split_env[0] == '1';
-        if (split_scatter) {
-            kern = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 2> : lattice_fwbw_sl_kernel<4, 8, 2>;
-            p.split = (int *)((char *)workspace + (size_t)(T + 2) * B * H * sizeof(float)) + B;
-        } else if (C <= H)
+        // + the label sort of FL == 1: cnt, cstart [Cpad]; pos, slab, inv [H]
+        const size_t lds_sl = (size_t)(4 * H + 6 * Cpad + 64 + 2 * H + 2 * Cpad + 3 * H) * sizeof(float);
+        if (C <= H)
             kern = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 1> : lattice_fwbw_sl_kernel<4, 8, 1>;
         else
             kern = Kmax <= 3 ? lattice_fwbw_sl_kernel<3, 8, 0> : lattice_fwbw_sl_kernel<4, 8, 0>;
         nt = 2 * H;
         lds = lds_sl > lds_mitm ? lds_sl : lds_mitm;
-        // Experimental (ASR_LATTICE_BAND=1): one-wave-per-chain kernel for band lattices.
-        // Correct (same tests) but slower today: 180 us vs 151 us on the B=512 mono
-        // numerator — a single wave per SIMD is issue-bound at ~1240 cycles per step.
-        const char *band_env = getenv("ASR_LATTICE_BAND");
-        if (band_env && band_env[0] == '1' && N <= 256 && C <= 64 && T > 0) {
-            // band lattices (CTC chains) first; it flags the utterances it has done
-            p.skip = (int *)((char *)workspace + (size_t)(T + 2) * B * H * sizeof(float));
-            hipLaunchKernelGGL((lattice_fwbw_band_kernel<4, 8>), dim3(B), dim3(128), 0,
-                               (hipStream_t)stream, p);
-        }
     } else if (N <= 1024 && Kmax <= 4) {
         kern = lattice_fwbw_kernel<4>;
         nt = round_up(N, 64);
@@ -1634,23 +1221,6 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
             return ASR_EUNSUPPORTED;
     }
     hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, s, p);
-    if (split_scatter) {
-        constexpr int FPW = 4;
-        const int nj = round_up(N, 64) / 64;
-        void (*sk)(FwbwParams);
-        switch (nj) {
-            case 1: sk = lattice_scatter_kernel<1, FPW>; break;
-            case 2: sk = lattice_scatter_kernel<2, FPW>; break;
-            case 3: sk = lattice_scatter_kernel<3, FPW>; break;
-            case 4: sk = lattice_scatter_kernel<4, FPW>; break;
-            case 5: sk = lattice_scatter_kernel<5, FPW>; break;
-            case 6: sk = lattice_scatter_kernel<6, FPW>; break;
-            case 7: sk = lattice_scatter_kernel<7, FPW>; break;
-            default: sk = lattice_scatter_kernel<8, FPW>; break;
-        }
-        hipLaunchKernelGGL(sk, dim3(B, (T + 4 * FPW - 1) / (4 * FPW)), dim3(256),
-                           (size_t)4 * Cpad * sizeof(float), s, p);
-    }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
