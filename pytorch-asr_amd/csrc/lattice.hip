@@ -35,9 +35,10 @@ struct FwbwParams {
 // in-arcs / out-arcs in registers for the whole scan.  KR == 0: states are
 // strided over the block and arcs are streamed from global memory (L2) every
 // frame (large shared graphs such as the CTC-G denominator).
+// ws_cols: columns of one [frame, utterance] row of the workspace (N for the stand-alone
+// kernel; the row width of the calling kernel's own layout when used as its fallback)
 template <int KR>
-__global__ void lattice_fwbw_kernel(FwbwParams p) {
-    extern __shared__ float smem[];
+__device__ __forceinline__ void lattice_fwbw_generic_body(const FwbwParams &p, float *smem, int ws_cols) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int N = p.N, C = p.C, Kin = p.Kin, Kout = p.Kout;
@@ -59,8 +60,8 @@ __global__ void lattice_fwbw_kernel(FwbwParams p) {
     const size_t tstride = (size_t)p.B * C;          // lp / grad frame stride
     const float *lp_b = p.lp + (size_t)b * C;
     float *grad_b = p.grad + (size_t)b * C;
-    const size_t astride = (size_t)p.B * N;
-    float *alphas_b = p.alphas + (size_t)b * N;
+    const size_t astride = (size_t)p.B * ws_cols;
+    float *alphas_b = p.alphas + (size_t)b * ws_cols;
     const float half_inf = p.neg_inf * 0.5f;
 
     // rows past the utterance end are zeros (fst_utils.py:448)
@@ -230,6 +231,12 @@ __global__ void lattice_fwbw_kernel(FwbwParams p) {
         s = block_sum(s, red);
         if (tid == 0) p.logZ_bwd[b] = m + __logf(s);
     }
+}
+
+template <int KR>
+__global__ void lattice_fwbw_kernel(FwbwParams p) {
+    extern __shared__ float smem[];
+    lattice_fwbw_generic_body<KR>(p, smem, p.N);
 }
 
 // ---------------------------------------------------------------------------
@@ -951,6 +958,9 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
             sum += __builtin_amdgcn_exp2f(al[i] + be[i] - mx);
         sum = block_sum(sum, red);
         logZ2 = mx + __builtin_amdgcn_logf(sum);
+        // = logsumexp_n(alpha_len + terminal) (fst_utils.py:445): the total over all paths
+        // is the same at every frame; taking it here saves a block reduction at the end
+        if (threadIdx.x == 0) p.logZ[b] = logZ2 * ASR_LN2;
     }
     __syncthreads();
 
@@ -997,20 +1007,6 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
         gcur += gstep;
         drain(S > 0);
     }
-    {   // logZ = logsumexp_n(alpha_len + terminal) (fst_utils.py:445)
-        const float *al = smem + (solo ? H : 0);
-        auto at = [&](int i) -> float {           // alpha_len + terminal of the state at position i
-            return al[i] + fmaxf(term[FL == 1 ? inv[i] : i], p.neg_inf) * ASR_L2E;
-        };
-        float mx = -INFINITY;
-        for (int i = threadIdx.x; i < N; i += blockDim.x) mx = fmaxf(mx, at(i));
-        mx = block_max(mx, red);
-        float sum = 0.f;
-        for (int i = threadIdx.x; i < N; i += blockDim.x)
-            sum += __builtin_amdgcn_exp2f(at(i) - mx);
-        sum = block_sum(sum, red);
-        if (threadIdx.x == 0) p.logZ[b] = (mx + __builtin_amdgcn_logf(sum)) * ASR_LN2;
-    }
     // fst_utils.py:476: logsumexp(alpha_0 + beta_0) == beta_0[0]
     if (p.logZ_bwd && isB && own && sid == 0) p.logZ_bwd[b] = breg * ASR_LN2;
 #ifdef ASR_SL_STAMPS
@@ -1022,6 +1018,8 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
     }
 #endif
 }
+
+#include "lattice_chain.inc"
 
 struct FwdParams {
     const float *lp;
@@ -1194,6 +1192,19 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     const size_t lds_mitm = (size_t)(4 * Npad + 4 * Cpad + 64) * sizeof(float);
     const bool fits32 = (size_t)T * B * C * 4 < (1ull << 31) &&
                         (size_t)(T + 2) * B * round_up(N, 64) * 4 < (1ull << 30);
+    // Opt-in (ASR_LATTICE_CHAIN=1): linear-domain kernel for CTC chain lattices, one wave per
+    // direction + one helper wave each.  Correct (tests/test_lattice_gpu.py) but slower than
+    // the 8-wave kernel below — 199 vs 126 us on the B=512 mono numerator: four states per
+    // lane put ~150 instructions per frame on ONE wave, and a wave issues at most one
+    // instruction per ~4 cycles whatever else the SIMD does (785 / 1380 cycles per frame in
+    // the two halves even at half a workgroup per CU).  DESIGN.md §4.1.
+    const char *chain_env = getenv("ASR_LATTICE_CHAIN");
+    if (chain_env && chain_env[0] == '1' && C <= 64 && N <= chain::NS && Kmax <= 3 && Bg == B &&
+        fits32 && T > 0) {
+        hipLaunchKernelGGL(lattice_fwbw_chain_kernel, dim3(B), dim3(256),
+                           (size_t)chain::LDS_WORDS * sizeof(float), s, p);
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
     if (N <= 512 && Kmax <= 4 && lds_mitm <= 160 * 1024 && fits32) {
         // state-labelled fast path; a workgroup whose graph fails the entry
         // check runs the generic body inside the same launch

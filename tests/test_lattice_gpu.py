@@ -389,3 +389,24 @@ def test_label_sorted_segmented_sums(oracle_lib, name, kw):
     assert feasible.sum() >= 2
     mask = (np.arange(T)[:, None] < lens[None, :]) & feasible[None, :]
     np.testing.assert_allclose(grad.sum(-1)[mask], 1.0, atol=max(2e-4, tol))
+
+
+def test_chain_kernel_linear_domain(monkeypatch, oracle_lib):
+    """ASR_LATTICE_CHAIN=1 routes mono-character CTC numerators through the linear-domain
+    chain kernel (csrc/lattice_chain.inc: (mantissa, exponent) pairs, one wave per direction,
+    helper waves, LDS-DMA rings); graphs of another shape, infeasible alignments and very
+    short utterances take its in-kernel generic fallback.  Same goldens, same tolerances."""
+    monkeypatch.setenv('ASR_LATTICE_CHAIN', '1')
+    g = golden('lattice_mono.npz')
+    mats = [g['gm%d' % i] for i in range(8)]
+    logZ, grad, zb = run_fwbw(g['lp'], g['lens'], mats, want_bwd=True)
+    np.testing.assert_allclose(logZ, g['fwbw_logZ'], rtol=RTOL_LOSS)
+    np.testing.assert_allclose(grad, g['fwbw_grad'], atol=grad_atol(logZ))
+    assert np.abs(zb - logZ).max() < 1e-3
+    for name, kw in [CASES[0], CASES[6], SORT_CASES[0], SORT_CASES[2]]:     # incl. ragged / infeasible
+        lp, lens, mats = _random_case(**kw)
+        want = oracle_lib.path_logsumexp(lp, lens, mats)
+        logZ, grad, zb = run_fwbw(lp, lens, mats, want_bwd=True)
+        np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
+        np.testing.assert_allclose(grad, want['grad'], atol=2 * grad_atol(want['logZ']))
+        np.testing.assert_allclose(zb, want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)

@@ -180,9 +180,9 @@ def test_ctc_decoder_advanced_matches_torch_ctc():
     assert res['decoded'] == ref.process_sequences(frames, elens)
 
 
-def test_skinny_projection_backward_matches_linear():
+def test_frame_projection_backward_matches_linear():
     """LutLinear's GPU backward (chunked dW / bias reductions) against F.linear's."""
-    from att_speech.modules.decoders.advanced_decoder import _SkinnyLinear
+    from att_speech.modules.decoders.advanced_decoder import _FrameProjection
     torch.manual_seed(1)
     d = dev()
     x = torch.randn(96, 64, 40, device=d)
@@ -192,7 +192,7 @@ def test_skinny_projection_backward_matches_linear():
     ref = [t.clone().requires_grad_() for t in (x, w, b)]
     torch.nn.functional.linear(*ref).backward(dy)
     got = [t.clone().requires_grad_() for t in (x, w, b)]
-    y = _SkinnyLinear.apply(*got)
+    y = _FrameProjection.apply(*got)
     y.backward(dy)
     assert torch.equal(y, torch.nn.functional.linear(x, w, b))
     for a, r in zip(got, ref):

@@ -13,6 +13,6 @@ tl = torch.from_numpy(lens).to(dev)
 for _ in range(3):
     z, grad, _ = _native.lattice_fwbw(lp, tl, g)
 torch.cuda.synchronize()
-st = grad[-1, :, :4].cpu().numpy()
+st = grad[167 if os.environ.get('CHAIN') else -1, :, :4].cpu().numpy()
 print('B=%d cycles: phase0 %.0f  mid %.0f  phase1 %.0f  tail %.0f  (per step: %.0f / %.0f)' % (
     (B,) + tuple(st.mean(0)) + (st[:, 0].mean() / 167, st[:, 2].mean() / 167)))
