@@ -66,6 +66,17 @@ def shard_batch(lengths, world_size):
     return shards
 
 
+def take_shard(features, feature_lens, texts, text_lens, indices):
+    """The rank's slice of a collated batch (`indices` from `shard_batch`): rows picked in
+    shard order, features trimmed to the shard's longest utterance — the encoder and the
+    lattice scan require `features.size(1) == feature_lens[0]` (deep_speech_2.py:152,
+    fst_utils.py:432) — and labels to its longest transcript."""
+    idx = torch.as_tensor(indices, dtype=torch.long)
+    lens, tlens = feature_lens[idx], text_lens[idx]
+    return (features[idx][:, :int(lens.max())].contiguous(), lens,
+            texts[idx][:, :max(1, int(tlens.max()))].contiguous(), tlens)
+
+
 def broadcast_parameters(module, src=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         for t in list(module.parameters()) + list(module.buffers()):

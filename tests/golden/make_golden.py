@@ -451,7 +451,49 @@ def golden_beam_lm():
     save('beam_lm.npz', **out)
 
 
+def golden_ctc_forward():
+    """Decode-side post-processing of ctc_forward.py:96-128 (hash -> blank transfer, biphone
+    tiling, block normalisation / marginalisation).  The script itself cannot be imported
+    (it parses arguments and opens Kaldi archives at import), so the block between the
+    `logprobs = ...numpy()` assignment and the archive writer is executed IN MEMORY from
+    the reference file's text with seeded inputs; inputs + outputs are stored per flag
+    combination."""
+    import textwrap
+    src = open(os.path.join(REF, 'ctc_forward.py')).read().split('\n')
+    first = next(i for i, l in enumerate(src) if l.strip().startswith('# transfer probability mass from hash'))
+    last = next(i for i, l in enumerate(src) if "for i in np.argsort(batch['uttids'])" in l)
+    block = compile(textwrap.dedent('\n'.join(src[first:last])), 'ctc_forward.py[block]', 'exec')
+    eps = float(next(l for l in src if l.startswith('EPSILON')).split('=')[1])
+    rng = np.random.default_rng(77)
+    out = {'EPSILON': np.float64(eps)}
+    combos = [dict(), dict(transfer_hash_prob=True), dict(imitate_biphones=True),
+              dict(imitate_biphones=True, block_normalize=True), dict(block_normalize=True),
+              dict(block_marginalize=True), dict(transfer_hash_prob=True, block_marginalize=True),
+              dict(transfer_hash_prob=True, imitate_biphones=True)]
+    for i, flags in enumerate(combos):
+        full = dict(transfer_hash_prob=False, imitate_biphones=False, block_normalize=False,
+                    block_marginalize=False)
+        full.update(flags)
+        c = 7 if full['imitate_biphones'] else 49
+        lp = torch.log_softmax(torch.from_numpy(
+            rng.standard_normal((11, 3, c)).astype(np.float32) * 3), -1).numpy()
+        ns = {'np': np, 'EPSILON': eps, 'args': types.SimpleNamespace(**full),
+              'logprobs': lp.copy(), 'print': lambda *a, **k: None}
+        exec(block, ns)
+        out['in_%d' % i] = lp
+        out['out_%d' % i] = np.asarray(ns['logprobs'])
+        out['flags_%d' % i] = np.array([full['transfer_hash_prob'], full['imitate_biphones'],
+                                        full['block_normalize'], full['block_marginalize']])
+    out['n'] = np.int32(len(combos))
+    save('ctc_forward.npz', **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1:                      # regenerate selected fixtures only
+        for name in sys.argv[1:]:
+            globals()['golden_' + name]()
+        sys.exit(0)
+    golden_ctc_forward()
     golden_lattice_mono()
     golden_lattice_bigram()
     golden_dense_bicontext()

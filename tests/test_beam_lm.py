@@ -98,53 +98,60 @@ def test_lm_fst_file_round_trips(tmp_path):
     assert t.input_symbols().find('<spc>') == 1
 
 
-def drive(bs, g, tag, n, nb):
+def _np(x):
+    return x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+def drive(bs, g, tag, n, nb, device='cpu'):
     for i in range(n):
-        l, m = bs.step(torch.from_numpy(g['logits'][i][:, :nb]).clone(),
-                       att_weights=torch.from_numpy(g['att'][i][:, :nb]).clone())
-        np.testing.assert_array_equal(l.numpy(), g[tag + '_letters'][i])
-        np.testing.assert_array_equal(m.numpy(), g[tag + '_maps'][i])
-        np.testing.assert_allclose(bs.scores.numpy(), g[tag + '_scores'][i], rtol=1e-5)
+        l, m = bs.step(torch.from_numpy(g['logits'][i][:, :nb]).clone().to(device),
+                       att_weights=torch.from_numpy(g['att'][i][:, :nb]).clone().to(device))
+        np.testing.assert_array_equal(l.cpu().numpy(), g[tag + '_letters'][i])
+        np.testing.assert_array_equal(m.cpu().numpy(), g[tag + '_maps'][i])
+        np.testing.assert_allclose(bs.scores.cpu().numpy(), g[tag + '_scores'][i], rtol=1e-5)
     assert len(bs.finished) == int(g[tag + '_nfinished'])
     np.testing.assert_allclose([float(f[0]) for f in bs.finished], g[tag + '_finished_scores'],
                                rtol=1e-5)
     assert [int(f[2]) for f in bs.finished] == g[tag + '_finished_beams'].tolist()
-    fl = [np.asarray(f[1]) for f in bs.finished]
+    fl = [_np(f[1]) for f in bs.finished]
     np.testing.assert_array_equal(np.concatenate(fl) if fl else np.zeros(0, np.int64),
                                   g[tag + '_finished_flat'])
     assert [len(f) for f in fl] == g[tag + '_finished_lens'].tolist()
-    np.testing.assert_array_equal(np.asarray(bs.best_finished[0]), g[tag + '_best'])
+    np.testing.assert_array_equal(_np(bs.best_finished[0]), g[tag + '_best'])
     np.testing.assert_allclose(float(bs.best_finished_scores[0]), float(g[tag + '_best_score']),
                                rtol=1e-5)
     for k, v in bs.best_finished_scores_elements.items():
         np.testing.assert_allclose(v, g[tag + '_el_' + k], rtol=1e-5, atol=1e-6)
-    np.testing.assert_array_equal(bs.estimations.numpy(), g[tag + '_estimations'])
+    np.testing.assert_array_equal(bs.estimations.cpu().numpy(), g[tag + '_estimations'])
     st = np.array([(b, k, v) for b, d in enumerate(bs.fst_states) for k, v in sorted(d.items())],
                   np.float64).reshape(-1, 3)
     np.testing.assert_allclose(st, g[tag + '_fst_states'], rtol=1e-10)
     if bs.coverage is not None:
-        np.testing.assert_allclose(bs.coverage.numpy(), g[tag + '_coverage'], rtol=1e-6)
+        np.testing.assert_allclose(bs.coverage.cpu().numpy(), g[tag + '_coverage'], rtol=1e-6)
     return bs
 
 
-def test_lm_fused_searches_match_reference():
+@pytest.mark.parametrize('device', ['cpu', pytest.param('cuda:0', marks=pytest.mark.gpu)])
+def test_lm_fused_searches_match_reference(device):
+    """on host tensors and (`-m gpu`) with the decoder's logits / alignments
+    living on the MI355X, as AttentionDecoderTCN.decode hands them over"""
     from att_speech.modules.beam_search import BeamSearchLM, GraphSearch, RescoreSearchLM
     g = golden('beam_lm.npz')
     lm, mapping = toy_lm(g), g['mapping'].tolist()
     C, beam, steps = 7, 4, g['logits'].shape[0]
-    dev = torch.device('cpu')
+    dev = torch.device(device)
     drive(BeamSearchLM(lm, 0.5, mapping, 0.3, 0.1, 0.2, 1, beam, dev, C, 0.6,
-                       keep_eos_score=False), g, 'lm', steps, beam)
+                       keep_eos_score=False), g, 'lm', steps, beam, device)
     drive(BeamSearchLM(lm, 0.8, mapping, 0.2, 0.1, 0.0, 1, beam, dev, C, 0.0,
-                       keep_eos_score=True), g, 'lmk', steps, beam)
+                       keep_eos_score=True), g, 'lmk', steps, beam, device)
     r = drive(RescoreSearchLM(g['sentence'].tolist(), lm, 0.5, mapping, 0.3, 0.1, 0.2, 1, 1, dev,
-                              C, 0.6, keep_eos_score=False), g, 'rs', 6, 1)
-    np.testing.assert_allclose(r.attentions.numpy(), g['rs_attentions'], rtol=1e-6)
+                              C, 0.6, keep_eos_score=False), g, 'rs', 6, 1, device)
+    np.testing.assert_allclose(r.attentions.cpu().numpy(), g['rs_attentions'], rtol=1e-6)
 
     def hash_dec(decoded, hs=2):
         return hash(tuple([-1] * (hs - len(decoded)) + decoded[-hs:].tolist()))
     gs = drive(GraphSearch(hash_dec, 0.3, lm, 0.5, mapping, 0.3, 0.1, 0.2, 1, beam, dev, C, 0.6,
-                           keep_eos_score=False), g, 'gs', steps, beam)
+                           keep_eos_score=False), g, 'gs', steps, beam, device)
     G = gs.get_graph()[0]
     V = np.array([[v[0], -1 if v[1] == '<sos>' else v[1], int(bool(v[4]))] for v in G['V']],
                  np.int64)

@@ -1,8 +1,36 @@
-"""Decode-side post-processing + Kaldi archive records against
-a numpy restatement of reference ctc_forward.py:96-131."""
+"""Decode-side post-processing + Kaldi archive records: against the
+reference's own ctc_forward.py:96-128 block (tests/golden/ctc_forward.npz — make_golden.py
+executes that block of the reference file in memory on seeded inputs) and against a numpy
+restatement of it."""
 import numpy as np
 import pytest
 import torch
+
+from conftest import golden
+
+
+def _check_against_reference_block(device, rtol, atol):
+    from att_speech.ctc_forward import postprocess_logprobs
+    g = golden('ctc_forward.npz')
+    assert abs(float(g['EPSILON']) - 1e-30) < 1e-36
+    for i in range(int(g['n'])):
+        th, ib, bn, bm = [bool(v) for v in g['flags_%d' % i]]
+        got = postprocess_logprobs(torch.from_numpy(g['in_%d' % i]).to(device),
+                                   transfer_hash_prob=th, imitate_biphones=ib,
+                                   block_normalize=bn, block_marginalize=bm).cpu().numpy()
+        want = g['out_%d' % i]
+        assert got.shape == want.shape, (i, got.shape, want.shape)
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg='combo %d' % i)
+
+
+def test_postprocess_matches_reference_block_cpu():
+    _check_against_reference_block('cpu', 1e-5, 1e-6)
+
+
+@pytest.mark.gpu
+def test_postprocess_matches_reference_block_gpu():
+    """the same on device tensors (the decode path keeps the log-probs on the GPU)"""
+    _check_against_reference_block('cuda:0', 1e-5, 2e-6)
 
 EPS = 1e-30
 

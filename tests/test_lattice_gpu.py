@@ -410,3 +410,65 @@ def test_chain_kernel_linear_domain(monkeypatch, oracle_lib):
         np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
         np.testing.assert_allclose(grad, want['grad'], atol=2 * grad_atol(want['logZ']))
         np.testing.assert_allclose(zb, want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
+
+
+def test_full_size_bichar_numerator_properties():
+    """The ctc_bi shape (C = 2401 bigram classes, T' = 334, L <= 100) at B = 64: per-frame
+    posteriors sum to one, zeros past the end, forward total == backward total, and the
+    bigram lattice with labels prev*49+cur collapses onto torch's mono CTC on repeat-free
+    transcripts when every bigram class is given its last symbol's mono log-prob
+    (lp_bi[c] = lp_mono[c % 49])."""
+    from att_speech import fst_utils as P
+    B, T, S = 64, 334, 49
+    rng = np.random.default_rng(5)
+    lens = np.sort(np.array([T - (b % 32) for b in range(B)], np.int32))[::-1].copy()
+    llens = np.array([100 - 2 * (b % 16) for b in range(B)])
+    mono = rng.integers(2, 49, size=(B, 100))
+    for j in range(1, 100):      # repeat-free transcripts: a repeated symbol is where the bigram
+        same = mono[:, j] == mono[:, j - 1]          # lattice and mono CTC differ (DESIGN.md §2)
+        mono[same, j] = 2 + (mono[same, j] - 2 + 1) % 47
+    prev = np.concatenate([np.zeros((B, 1), mono.dtype), mono[:, :-1]], 1)
+    labs = prev * S + mono
+    lp_mono = torch.log_softmax(torch.from_numpy(rng.standard_normal((T, B, S)).astype(np.float32)), -1)
+    lp = lp_mono.repeat(1, 1, S).contiguous()            # [T, B, 2401]: class c -> lp_mono[c % 49]
+    pg = P.CTCGraphGen(context_order=2, num_symbols=S)
+    mats = [m.numpy() for m in pg.get_training_matrices_batch(labs, llens)]
+    logZ, grad, zb = run_fwbw(lp.numpy(), lens, mats, want_bwd=True)
+    np.testing.assert_allclose(zb, logZ, rtol=RTOL_LOSS)
+    mask = np.arange(T)[:, None] < lens[None, :]
+    np.testing.assert_allclose(grad.sum(-1)[mask], 1.0, atol=1e-3)
+    assert not grad[~mask].any() and grad.min() >= 0.0
+    want = torch.nn.functional.ctc_loss(
+        lp_mono.to(dev()), torch.from_numpy(mono).to(dev()), torch.from_numpy(lens).long(),
+        torch.from_numpy(llens), reduction='none').cpu().numpy()
+    np.testing.assert_allclose(-logZ, want, rtol=RTOL_LOSS)
+
+
+def test_full_size_grouped_denominator_properties():
+    """The CTC-G denominator (2401 states x 51 arcs, group-factored kernels) at T' = 334,
+    B = 16: posteriors of a frame sum to one, zeros past the end, forward == backward total,
+    the alpha-only scan gives the same total, and Viterbi <= logsumexp."""
+    from att_speech import _native, fst_utils as P
+    B, T, S = 16, 334, 49
+    rng = np.random.default_rng(6)
+    pg = P.CTCGraphGen(context_order=2, num_symbols=S)
+    tagged = pg.get_decoding_matrices()
+    d = dev()
+    gg = _native.GroupedGraph(tagged.grouped, d)
+    x = torch.from_numpy(rng.standard_normal((T, B, S * S)).astype(np.float32))
+    lp = torch.log_softmax(x, -1).to(d)
+    lens = np.sort(np.array([T - 7 * b for b in range(B)], np.int32))[::-1].copy()
+    tl = torch.from_numpy(lens).to(d)
+    logZ, grad, zb = _native.grouped_fwbw(lp, tl, gg, -1e20, want_bwd_total=True)
+    s, _ = _native.grouped_forward(lp, tl, gg, -1e20)
+    v, _ = _native.grouped_forward(lp, tl, gg, -1e20, viterbi=True, want_path=True)
+    torch.cuda.synchronize()
+    logZ, grad, zb, s, v = [a.cpu().numpy() for a in (logZ, grad, zb, s, v)]
+    np.testing.assert_allclose(zb, logZ, rtol=RTOL_LOSS)
+    np.testing.assert_allclose(s, logZ, rtol=RTOL_LOSS)
+    assert (v <= logZ + 1e-3).all()
+    mask = np.arange(T)[:, None] < lens[None, :]
+    np.testing.assert_allclose(grad.sum(-1)[mask], 1.0, atol=1e-3)
+    assert not grad[~mask].any() and grad.min() >= 0.0
+    # locally normalised inputs: the sum over ALL label sequences of the decoding graph is <= 1
+    assert (logZ <= 1e-3).all()

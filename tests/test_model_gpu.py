@@ -197,3 +197,52 @@ def test_frame_projection_backward_matches_linear():
     assert torch.equal(y, torch.nn.functional.linear(x, w, b))
     for a, r in zip(got, ref):
         torch.testing.assert_close(a.grad, r.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_train_step_with_bucket_and_hooks_on_the_device(oracle_lib):
+    """SURVEY.md §8f N1 on the GPU: SpeechModel + FlatGradBucket + GradientClipping +
+    PolyakDecay through dp.train_step (world size 1).  The clipped flat bucket equals
+    clip_grad_norm_ on an identical replica without a bucket, a step over skip_step_norm
+    leaves the weights alone, otherwise Adam moves them and the Polyak average follows."""
+    from att_speech.dp import FlatGradBucket, train_step
+    from att_speech.models import SpeechModel
+    from att_speech.modules.hooks import GradientClipping, PolyakDecay
+    torch.manual_seed(21)
+    B, T, L = 4, 120, 8
+    feats, lens, texts, llens = make_batch(B, T, 49, L, 1, 13)
+    model = SpeechModel(ENC, DEC_MONO, sample_batch(B=2, T=T), 49, VOCAB).to(dev())
+    twin = copy.deepcopy(model)
+    args = ((feats.to(dev()), lens, None, texts, llens), {})
+    # (1) clipping on the flat bucket == clip_grad_norm_ on separate gradients
+    bucket = FlatGradBucket(model.parameters())
+    hook = GradientClipping(clip_norm=0.5, skip_step_norm=1e12)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    out, skipped = train_step(model, opt, args, hooks=[hook], bucket=bucket)
+    assert not skipped and hook.gstats.clips == 1
+    assert abs(float(bucket.flat.norm()) - 0.5) < 1e-3
+    twin(*args[0])['loss'].backward()
+    total = float(torch.nn.utils.clip_grad_norm_(twin.parameters(), 0.5))
+    assert abs(hook.gstats.norms[0] - total) <= 2e-3 * total
+    for (k, p), q in zip(model.named_parameters(), twin.parameters()):
+        scale = max(float(q.grad.abs().max()), 1e-6)
+        assert float((p.grad - q.grad).abs().max()) <= 2e-2 * scale, k     # bf16 encoder, two runs
+    # (2) skip: weights and optimizer state untouched; (3) a normal step moves them
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    polyak = PolyakDecay(decay_rates=[0.5])
+    polyak.pre_run(model, opt)
+    skipper = GradientClipping(clip_norm=1e12, skip_step_norm=1e-9)
+    out, skipped = train_step(model, opt, args, hooks=[skipper, polyak], bucket=bucket)
+    assert skipped and all(torch.equal(p, before[k]) for k, p in model.named_parameters())
+    out, skipped = train_step(model, opt, args,
+                              hooks=[GradientClipping(clip_norm=1e12, skip_step_norm=1e12), polyak],
+                              bucket=bucket)
+    assert not skipped
+    w_new, w_old = model.state_dict()['decoder.fc.0.module.0.weight'], before['decoder.fc.0.module.0.weight']
+    assert not torch.equal(w_new, w_old)
+    avg = getattr(model, PolyakDecay.dict_name(0.5))['decoder.fc.0.module.0.weight']
+    # two post_optimizer_step calls: avg <- old (no step), then avg <- 0.5 old + 0.5 new
+    torch.testing.assert_close(avg, 0.5 * w_old + 0.5 * w_new, rtol=1e-5, atol=1e-7)
+    losses = [float(train_step(model, opt, args, hooks=[polyak], bucket=bucket)[0]['loss'])
+              for _ in range(5)]
+    assert losses[-1] < losses[0]
