@@ -18,6 +18,8 @@ Prints ONE JSON line on rank 0 (see the contract in the task statement), with
   roofline_bichar — the same kernel on the bi-char numerator (C = 2401, B = 512),
                     launched alone after the timed region (N = 1 only);
   roofline_mfma   — dense flops of the step / step time / 2.5 PFLOP/s (bf16 dense peak);
+  decode          — BASELINE config 4 beside the headline: utterances/s of the TCN attention
+                    decoder with beam 10 (N = 1 only);
   loss_delta      — |loss_gpu - loss_cpu| / |loss_cpu| of one small batch, product
                     model on the GPU vs the fp32 CPU composition with the same weights
                     (end to end, and decoder + lattice on identical encoder output);
@@ -262,6 +264,36 @@ def bichar_numerator_roofline(dev, B=512, Tp=334, iters=10):
             'traffic': None, 'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': ms}
 
 
+def tcn_decode_rate(dev, B=64, T=1000, beam=10, steps=120):
+    """BASELINE config 4: encoder + AttentionDecoderTCN (lattice_decoding/tcn.yaml dimensions)
+    with beam search on one GPU; random weights rarely emit EOS, so the label-step budget is
+    fixed.  Utterances per second over whole `decode` calls."""
+    from att_speech.models import SpeechModel
+    feats, lens, texts, llens = synthetic_batch(B, T, 0, 1)
+    enc_cfg, _ = model_config(1, None)
+    dec_cfg = dict(class_name='att_speech.modules.tcn.AttentionDecoderTCN', att_hidden_size=64,
+                   beam_size=beam, dilation_sizes=[1, 2], dropout_p=0.3, kernel_size=3,
+                   length_normalization=0.6, tcn_hidden_size=384, tcn_layers_per_block=2)
+    torch.manual_seed(0)
+    sb = {'features': feats[:2].clone(), 'features_lengths': lens[:2].clone(), 'spkids': None}
+    model = SpeechModel(enc_cfg, dec_cfg, sb, S, [str(i) for i in range(S)]).to(dev).eval()
+    model.decoder.TRANSCRIPTION_LEN_GUARD = steps
+    f = feats.to(dev)
+    with torch.no_grad():
+        model.decode(f, lens, None)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        n = 3
+        for _ in range(n):
+            model.decode(f, lens, None)
+        torch.cuda.synchronize()
+    dt = (time.time() - t0) / n
+    return {'metric': 'stage-2 decode: DeepSpeech2 encoder + TCN/local-attention decoder, beam search',
+            'value': B / dt, 'unit': 'utt/s', 'ms_per_batch': dt * 1e3, 'batch': B, 'beam': beam,
+            'label_steps': steps, 'frames': T,
+            'workload': 'lattice_decoding/tcn.yaml dimensions, random weights, fixed label-step budget'}
+
+
 def self_launch(a, argv):
     """`python bench.py --gpus N` with no rank environment: start the N ranks as a
     child `torch.distributed.run` (this process has not touched the GPU and never
@@ -354,7 +386,7 @@ def main():
     ap.add_argument('--no-hooks', action='store_true',
                     help='leave out GradientClipping / PolyakDecay (recipe hooks)')
     ap.add_argument('--no-extra', action='store_true',
-                    help='leave out the bi-char numerator roofline launch')
+                    help='leave out the bi-char numerator roofline launch and the decode rate')
     ap.add_argument('--dry-run-launcher', action='store_true', help=argparse.SUPPRESS)
     a = ap.parse_args()
 
@@ -523,6 +555,9 @@ def main():
             torch.cuda.empty_cache()
             progress('bi-char numerator roofline launch')
             res['roofline_bichar'] = bichar_numerator_roofline(dev)
+            torch.cuda.empty_cache()
+            progress('stage-2 decode rate')
+            res['decode'] = tcn_decode_rate(dev)
         if world == 1 and not a.no_cpu_baseline and a.workload != 'ctcg_bi_cde':
             progress('loss delta + timing the CPU baseline (about 25 s)')
             res['cpu_baseline'], res['loss_delta'] = cpu_baseline(T, order, dev, model.state_dict())

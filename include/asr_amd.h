@@ -285,6 +285,49 @@ int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_bias, int B,
                        void *dx, float *dgamma, float *dbeta, float *dconv_bias,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
+/*
+ * One label step of the TCN / local-attention decoder for every live hypothesis
+ * (replaces LocalAttention.forward, reference att_speech/modules/tcn.py:193-230, and the
+ * context reduction of AttentionDecoderTCN.enc_step, :465-474).  Hypothesis h = u * beam + k
+ * belongs to utterance u.
+ *   eproj   [T, B, A]   encoded_to_hidden(encoded), per utterance, time-major
+ *   enc     [T, B, E]   encoder output;  enc_lens [B]
+ *   filt    [B*beam, A, Kf]  lm_to_kernel(lm_state) (Kf = 32 taps), glob [B*beam, A] lm_to_global(lm_state)
+ *   w_score [A], b_score: hidden_to_score;  temperature: LocalAttention.temperature
+ *   att_prev [B*beam, T] previous alignments, one row per hypothesis; parent [B*beam] (or
+ *           null): hypothesis h continues row parent[h] (the beam's re-indexing, :551)
+ *   att_new [B*beam, T]  softmax_t( w . tanh(eproj_t + (a_prev * filt)(t) + glob) * temperature + pad_t )
+ *   context [B*beam, E]  sum_t att_new[t] enc[t]
+ */
+int asr_tcn_attention_step_f32(const float *eproj, const float *enc, const int32_t *enc_lens,
+                               const float *filt, const float *glob, const float *w_score,
+                               float b_score, float temperature,
+                               const float *att_prev, const int32_t *parent,
+                               int T, int B, int beam, int A, int Kf, int E,
+                               float *att_new, float *context, void *stream);
+
+/*
+ * One step of BeamSearch for every utterance, without a host read-back (replaces
+ * BeamSearch.step + _save_best_finished, reference att_speech/modules/beam_search.py:58-124,
+ * 147-175).  logits [B*beam, C] (class C-1 = EOS); scores_in / scores_out [B*beam] running
+ * scores (distinct buffers); est_in / est_out [B*beam, Lcap] label histories (distinct
+ * buffers, `step` labels each on entry); len_div = step ** length_normalization.
+ * Per utterance: finished_count [B], best_score [B] (init -inf; the RAW EOS score, the
+ * reference's aliasing quirk), best_len [B], best_tokens [B, Lcap].  Outputs new_input
+ * [B*beam] (chosen labels), parent [B*beam] (flat index of the hypothesis each survivor
+ * extends).  done_and_scratch [3] int32, zero before the first step: word 0 becomes 1 after
+ * the step in which every utterance reached finished_count >= beam; calls with the flag set
+ * change nothing, so a host polling it every few steps sees the reference's results; word 2
+ * counts the steps that took effect (the final histories are in the buffer written by the
+ * last of them), word 1 is scratch.
+ * Ties in the top-k go to the lower candidate index.  beam <= 32, beam * (C-1) <= 2048.
+ */
+int asr_beam_step_f32(const float *logits, const float *scores_in, float *scores_out,
+                      const int32_t *est_in, int32_t *est_out, int step, int B, int beam, int C,
+                      int Lcap, float len_div, int32_t *finished_count, float *best_score,
+                      int32_t *best_len, int32_t *best_tokens, int32_t *new_input,
+                      int32_t *parent, int32_t *done_and_scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

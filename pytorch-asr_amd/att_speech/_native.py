@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -40,6 +40,10 @@ _SIGNATURES = {
     'asr_log_softmax_bwd_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'asr_sub_rowmax_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_argmax_rows_f32': (_i, [_vp, _i64, _i, _vp, _vp]),
+    'asr_tcn_attention_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
+                                        _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'asr_beam_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'asr_ctc_graph_build': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f] + [_vp] * 8),
     'asr_lattice_grouped_workspace_bytes': (_i64, [_i, _i, _i, _i]),
     'asr_lattice_grouped_fwbw_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i] + [_vp] * 8 +
@@ -473,3 +477,36 @@ def bn_act_bwd(x, gamma, beta, mean, invstd, training, lo, hi, dy, time_major=Fa
                                _p(dgamma), _p(dbeta), _p(dcb), _p(ws), nbytes, _stream()),
           'asr_bn_act_bwd_f32')
     return dx, dgamma, dbeta, dcb
+
+
+def tcn_attention_step(eproj, enc, enc_lens, filt, glob, w_score, b_score, temperature,
+                       att_prev, parent, beam):
+    """asr_tcn_attention_step_f32 -> (att_new [B*beam, T], context [B*beam, E])."""
+    eproj, enc = _dev(eproj, torch.float32, 'eproj'), _dev(enc, torch.float32, 'enc')
+    filt, glob = _dev(filt, torch.float32, 'filt'), _dev(glob, torch.float32, 'glob')
+    att_prev = _dev(att_prev, torch.float32, 'att_prev')
+    w_score = _dev(w_score, torch.float32, 'w_score')
+    enc_lens = _dev(enc_lens, torch.int32, 'enc_lens')
+    T, B, A = eproj.shape
+    E = enc.shape[2]
+    hyps = B * beam
+    taps = filt.numel() // (hyps * A)
+    att_new = torch.empty((hyps, T), dtype=torch.float32, device=enc.device)
+    ctx = torch.empty((hyps, E), dtype=torch.float32, device=enc.device)
+    par = None if parent is None else _dev(parent, torch.int32, 'parent')
+    check(lib().asr_tcn_attention_step_f32(
+        _p(eproj), _p(enc), _p(enc_lens), _p(filt), _p(glob), _p(w_score), float(b_score),
+        float(temperature), _p(att_prev), _p(par), T, B, beam, A, taps, E, _p(att_new), _p(ctx),
+        _stream()), 'asr_tcn_attention_step_f32')
+    return att_new, ctx
+
+
+def beam_step(logits, scores_in, scores_out, est_in, est_out, step, B, beam, len_div, state):
+    """asr_beam_step_f32; `state` = dict of the per-utterance device arrays (finished_count,
+    best_score, best_len, best_tokens, new_input, parent, done)."""
+    C = logits.shape[-1]
+    check(lib().asr_beam_step_f32(
+        _p(logits), _p(scores_in), _p(scores_out), _p(est_in), _p(est_out), int(step), B, beam, C,
+        est_in.shape[1], float(len_div), _p(state['finished_count']), _p(state['best_score']),
+        _p(state['best_len']), _p(state['best_tokens']), _p(state['new_input']),
+        _p(state['parent']), _p(state['done']), _stream()), 'asr_beam_step_f32')

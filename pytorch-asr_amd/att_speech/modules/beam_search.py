@@ -456,3 +456,70 @@ class GraphSearch(BeamSearchLM):
                         E.append((parent, me, kind))
             G.append({'V': V, 'E': E})
         return G
+
+
+class DeviceBeamSearch(object):
+    """Plain BeamSearch (reference beam_search.py:13-182) with ALL of its state on the MI355X
+    and no host read-back inside a step (`asr_beam_step_f32`): running scores, label
+    histories (double-buffered `[B*beam, Lcap]`), per-utterance finished counts and best
+    finished hypotheses.  `step` only enqueues a launch; `poll_finished` reads the
+    device-side flag (the caller decides how often); `finalize` copies the results into the
+    attributes the reference's object exposes (`finished_count`, `best_finished`,
+    `best_finished_scores`, `best_finished_scores_elements`, `estimations`, `scores`)."""
+
+    def __init__(self, batch_size, beam_size, device, num_classes, length_normalization,
+                 max_steps):
+        from att_speech import _native
+        self._native = _native
+        self.batch_size, self.beam_size, self.num_classes = batch_size, beam_size, num_classes
+        self.length_normalization = length_normalization
+        hyps, cap = batch_size * beam_size, max_steps + 1
+        i32 = dict(dtype=torch.int32, device=device)
+        self._scores = [torch.zeros(hyps, device=device), torch.zeros(hyps, device=device)]
+        self._est = [torch.zeros((hyps, cap), **i32), torch.zeros((hyps, cap), **i32)]
+        self._state = {
+            'finished_count': torch.zeros(batch_size, **i32),
+            'best_score': torch.full((batch_size,), float('-inf'), device=device),
+            'best_len': torch.zeros(batch_size, **i32),
+            'best_tokens': torch.zeros((batch_size, cap), **i32),
+            'new_input': torch.zeros(hyps, **i32), 'parent': torch.zeros(hyps, **i32),
+            'done': torch.zeros(3, **i32)}
+        self._step = 0
+        self.coverage = None
+        self.print_debug = False
+        self.estimations = None
+        self.scores = self._scores[0]
+
+    def step(self, logits, *args, **kwargs):
+        """logits [1, B*beam, C] or [B*beam, C] -> (chosen labels, parent hypothesis) as
+        int32 device tensors (valid until the next step)."""
+        s = self._step
+        logits = logits.reshape(-1, self.num_classes).contiguous()
+        len_div = float(s ** self.length_normalization) if s > 0 else 1.0
+        self._native.beam_step(logits, self._scores[s & 1], self._scores[(s + 1) & 1],
+                               self._est[s & 1], self._est[(s + 1) & 1], s, self.batch_size,
+                               self.beam_size, len_div, self._state)
+        self._step = s + 1
+        return self._state['new_input'], self._state['parent']
+
+    def poll_finished(self):
+        return bool(int(self._state['done'][0].item()))
+
+    has_finished = poll_finished
+
+    def get_graph(self):
+        return None
+
+    def finalize(self):
+        st = self._state
+        done = st['done'].cpu().tolist()
+        eff = int(done[2])                       # steps that took effect
+        self.finished_count = st['finished_count'].cpu().tolist()
+        lens = st['best_len'].cpu().tolist()
+        toks = st['best_tokens'].cpu().long()
+        self.best_finished = [toks[b, :lens[b]] if lens[b] > 0 else [] for b in range(self.batch_size)]
+        self.best_finished_scores = [float(v) for v in st['best_score'].cpu().tolist()]
+        self.best_finished_scores_elements = {'acoustic': self.best_finished_scores}
+        self.estimations = self._est[eff & 1][:, :eff].long()
+        self.scores = self._scores[eff & 1]
+        return self

@@ -22,6 +22,8 @@ arithmetic layout are this build's:
 """
 from __future__ import absolute_import, division, print_function
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -96,6 +98,59 @@ class TCN(nn.Module):
 
     def forward(self, x):                       # [time, batch, channels] in and out
         return self.network(x.permute(1, 2, 0)).permute(2, 0, 1)
+
+    def last_step_plan(self, steps):
+        """Operands for `last_step` over a window of `steps` frames: per block the frames its
+        output is needed at, and per convolution (weight [taps*Cin, Cout] with the
+        weight-norm already applied, bias, tap source indices).  Only what the LAST output
+        frame depends on is computed — 18 of the 28 frame x layer pairs for the tcn.yaml
+        stack — as dense products over all hypotheses."""
+        blocks = list(self.network)
+        need = [None] * (len(blocks) + 1)
+        need[-1] = [steps - 1]
+        plans = [None] * len(blocks)
+        for bi in range(len(blocks) - 1, -1, -1):
+            convs = list(blocks[bi].net.values())
+            outs, cur = [], need[bi + 1]
+            for conv in reversed(convs):
+                taps, dil = conv.kernel_size[0], conv.dilation[0]
+                src = sorted({t - (taps - 1 - j) * dil for t in cur for j in range(taps)} - set(
+                    range(-steps * taps * dil, 0)))
+                outs.append((conv, cur, src))
+                cur = src
+            need[bi] = sorted(set(cur) | set(need[bi + 1]))          # + the residual input
+            layers, avail = [], need[bi]
+            for conv, out_pos, _ in reversed(outs):
+                taps, dil = conv.kernel_size[0], conv.dilation[0]
+                w = torch._weight_norm(conv.weight_v, conv.weight_g, 0).detach()
+                # row index into [zero frame] + available frames, per (output frame, tap)
+                idx = [[(avail.index(t - (taps - 1 - j) * dil) + 1) if t - (taps - 1 - j) * dil >= 0 else 0
+                        for j in range(taps)] for t in out_pos]
+                layers.append((w.permute(2, 1, 0).reshape(-1, w.size(0)).contiguous(),
+                               conv.bias.detach(), torch.tensor(idx, device=w.device)))
+                avail = out_pos
+            res_idx = torch.tensor([need[bi].index(t) for t in need[bi + 1]], device=w.device)
+            plans[bi] = (layers, res_idx, blocks[bi].downsample)
+        return need[0], plans
+
+    @staticmethod
+    def last_step(x, plan):
+        """x [steps, hyp, C] -> LM state of the last frame [hyp, C] (eval mode)."""
+        first_need, plans = plan
+        cur = x[first_need] if len(first_need) != x.size(0) else x        # [n, hyp, C]
+        for layers, res_idx, downsample in plans:
+            y = cur
+            for weight, bias, idx in layers:
+                padded = torch.cat((torch.zeros_like(y[:1]), y))            # frame 0 = zeros
+                cols = padded[idx]                                          # [out, taps, hyp, C]
+                n_out, taps, hyps, ch = cols.shape
+                cols = cols.permute(0, 2, 1, 3).reshape(n_out * hyps, taps * ch)
+                y = torch.relu(torch.addmm(bias, cols, weight)).view(n_out, hyps, -1)
+            shortcut = cur[res_idx]
+            if downsample is not None:
+                shortcut = downsample(shortcut.permute(1, 2, 0)).permute(2, 0, 1)
+            cur = torch.relu(y + shortcut)
+        return cur[-1]
 
 
 class LocalAttention(nn.Module):
@@ -325,9 +380,72 @@ class AttentionDecoderTCN(nn.Module):
                                keep_eos_score=self.keep_eos_score)
         return BeamSearchLM(*fused, keep_eos_score=self.keep_eos_score)
 
+    def _native_decode_ok(self, encoded):
+        C, beam = self.num_classes, self.beam_size
+        if os.environ.get('ASR_TCN_NATIVE', '1') == '0':     # A/B switch: torch ops + BeamSearch
+            return False
+        return (encoded.is_cuda and not self.lm and not self.training
+                and not self.attn.force_forward and self.attn.kernel_size == 32
+                and beam <= 32 and beam * (C - 1) <= 2048 and encoded.dtype == torch.float32)
+
+    def _decode_native(self, encoded, encoded_lens, return_attention, poll_every=8):
+        """The MI355X decode loop for the plain beam search: per label step the LM state of
+        the last frame as dense products (TCN.last_step), ONE launch for the local attention
+        + context (asr_tcn_attention_step_f32), the output MLP, ONE launch for the beam
+        bookkeeping (asr_beam_step_f32) — no host read-back inside a step; the all-finished
+        flag is polled every `poll_every` steps (steps behind the flag change nothing)."""
+        from att_speech import _native
+        from att_speech.modules.beam_search import DeviceBeamSearch
+        T, B, E = encoded.shape
+        beam, dev, attn = self.beam_size, encoded.device, self.attn
+        hyps = B * beam
+        lens = torch.as_tensor(encoded_lens).to(dev, torch.int32)
+        search = DeviceBeamSearch(B, beam, dev, self.num_classes, self.length_normalization,
+                                  self.TRANSCRIPTION_LEN_GUARD)
+        # per-utterance operands (the reference repeats them per hypothesis, :449-456)
+        (eproj, _), first = attn.init_attention(encoded, lens)
+        eproj = eproj.contiguous()
+        enc = encoded.contiguous()
+        att = first.t().repeat_interleave(beam, dim=0).contiguous()          # [hyp, T]
+        plan = self.tcn.last_step_plan(self.tcn.eff_history)
+        w_att = torch.cat((attn.lm_to_kernel.weight, attn.lm_to_global.weight)).detach()
+        b_att = torch.cat((attn.lm_to_kernel.bias, attn.lm_to_global.bias)).detach()
+        n_filt = attn.lm_to_kernel.out_features
+        w_score = attn.hidden_to_score.weight.detach().reshape(-1).contiguous()
+        b_score = float(attn.hidden_to_score.bias)
+        history = enc.new_zeros(self.tcn.eff_history, hyps, self.tcn_hidden_size)
+        parent = None
+        trace_att = [first.repeat_interleave(beam, dim=1).detach()] if return_attention else None
+        trace_logits = []
+        for step in range(self.TRANSCRIPTION_LEN_GUARD):
+            lm_state = TCN.last_step(history, plan)
+            fg = torch.addmm(b_att, lm_state, w_att.t())
+            att, context = _native.tcn_attention_step(
+                eproj, enc, lens, fg[:, :n_filt].contiguous(), fg[:, n_filt:].contiguous(),
+                w_score, b_score, attn.temperature, att, parent, beam)
+            logits = self._step_output(lm_state, context)
+            chosen, parent = search.step(logits)
+            if return_attention:
+                trace_logits.append(logits.detach()[None])
+                trace_att.append(att.t().detach())
+            history = torch.cat((history[1:].index_select(1, parent.long()),
+                                 self.embedding(chosen.long())[None]))
+            if (return_attention or step % poll_every == poll_every - 1) and search.poll_finished():
+                break
+        search.finalize()
+        out = {'decoded': search.best_finished,
+               'decoded_scores': search.best_finished_scores_elements,
+               'loss': torch.Tensor(search.best_finished_scores).mean()}
+        if return_attention:
+            out.update(attweights=trace_att, logits=trace_logits)
+        out.update(coverage=None, graph=None, beam_search=search)
+        return out
+
     def decode(self, encoded, encoded_lens, texts=None, text_lens=None,
                return_attention=False, print_debug=False, **kwargs):
         """Beam search over label steps (:476-585), at most TRANSCRIPTION_LEN_GUARD of them."""
+        if self._native_decode_ok(encoded) and not print_debug:
+            return self._decode_native(encoded, encoded_lens, return_attention)
         search = self._make_search(encoded.size(1), encoded.device)
         search.print_debug = print_debug
         state = self.enc_initial_state(encoded, encoded_lens, self.beam_size, encoded.size(1))
