@@ -286,6 +286,27 @@ int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_bias, int B,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
+ * The 7x7, 32 -> 32 channel convolution of the DeepSpeech2 front-end (reference
+ * att_speech/modules/encoders/deep_speech_2.py:60-73, Conv2d(32, 32, (7, 7), stride
+ * (stride_h, 1)), stride_h in {1, 3}) on channels-last bf16 with fp32 accumulation, bias-free
+ * (the bias is folded into asr_bn_act_*):
+ *   x [B, H, W, 32] bf16, w [32, 32, 7, 7] f32 (nn.Conv2d layout), y [B, Ho, Wo, 32] bf16,
+ *   Ho = (H - 7) / stride_h + 1, Wo = W - 6 (<= 48).
+ * fwd: y = conv(x, w);  bwd_data: dx = conv_transpose(dy, w) [B, H, W, 32] bf16;
+ * wgrad: dw [32, 32, 7, 7] f32 = sum over the batch of dy (x) x (overwritten).
+ * workspace: asr_conv7x7c32_workspace_bytes() (packed weight fragments / partial sums).
+ */
+int64_t asr_conv7x7c32_workspace_bytes(void);
+int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int H, int W, int stride_h,
+                            void *y, void *workspace, int64_t workspace_bytes, void *stream);
+/* stride_h = 3 only (the shape the encoder uses); H, W are the INPUT's (dx's) extents */
+int asr_conv7x7c32_bwd_data_bf16(const void *dy, const float *w, int B, int H, int W,
+                                 int stride_h, void *dx, void *workspace,
+                                 int64_t workspace_bytes, void *stream);
+int asr_conv7x7c32_wgrad_bf16(const void *x, const void *dy, int B, int H, int W, int stride_h,
+                              float *dw, void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
  * One label step of the TCN / local-attention decoder for every live hypothesis
  * (replaces LocalAttention.forward, reference att_speech/modules/tcn.py:193-230, and the
  * context reduction of AttentionDecoderTCN.enc_step, :465-474).  Hypothesis h = u * beam + k

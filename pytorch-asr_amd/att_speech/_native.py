@@ -40,6 +40,10 @@ _SIGNATURES = {
     'asr_log_softmax_bwd_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'asr_sub_rowmax_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_argmax_rows_f32': (_i, [_vp, _i64, _i, _vp, _vp]),
+    'asr_conv7x7c32_workspace_bytes': (_i64, []),
+    'asr_conv7x7c32_fwd_bf16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    'asr_conv7x7c32_bwd_data_bf16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    'asr_conv7x7c32_wgrad_bf16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     'asr_tcn_attention_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                         _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_beam_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f,
@@ -510,3 +514,59 @@ def beam_step(logits, scores_in, scores_out, est_in, est_out, step, B, beam, len
         est_in.shape[1], float(len_div), _p(state['finished_count']), _p(state['best_score']),
         _p(state['best_len']), _p(state['best_tokens']), _p(state['new_input']),
         _p(state['parent']), _p(state['done']), _stream()), 'asr_beam_step_f32')
+
+
+def _nhwc_bf16(t, what):
+    """logical [B, C, H, W] bf16 tensor in channels-last memory -> (tensor, B, C, H, W)"""
+    if not t.is_cuda:
+        raise NativeLibraryError("%s must live on the MI355X" % what)
+    if t.dtype != torch.bfloat16:
+        t = t.to(torch.bfloat16)
+    t = t.contiguous(memory_format=torch.channels_last)
+    return (t,) + tuple(t.shape)
+
+
+def conv7x7c32_fwd(x, weight, stride_h):
+    """asr_conv7x7c32_fwd_bf16: x logical [B, 32, H, W] (channels-last bf16), weight
+    [32, 32, 7, 7] f32 -> y logical [B, 32, Ho, Wo] channels-last bf16."""
+    x, B, C, H, W = _nhwc_bf16(x, 'x')
+    weight = _dev(weight, torch.float32, 'weight')
+    Ho, Wo = (H - 7) // stride_h + 1, W - 6
+    y = torch.empty((B, 32, Ho, Wo), dtype=torch.bfloat16, device=x.device,
+                    memory_format=torch.channels_last)
+    L = lib()
+    nbytes = L.asr_conv7x7c32_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(L.asr_conv7x7c32_fwd_bf16(_p(x), _p(weight), B, H, W, int(stride_h), _p(y), _p(ws),
+                                    nbytes, _stream()), 'asr_conv7x7c32_fwd_bf16')
+    return y
+
+
+def conv7x7c32_bwd_data(dy, weight, H, W, stride_h):
+    """asr_conv7x7c32_bwd_data_bf16: dy logical [B, 32, Ho, Wo] -> dx logical [B, 32, H, W]
+    (channels-last bf16)."""
+    dy, B, C, Ho, Wo = _nhwc_bf16(dy, 'dy')
+    weight = _dev(weight, torch.float32, 'weight')
+    assert Ho == (H - 7) // stride_h + 1 and Wo == W - 6
+    dx = torch.empty((B, 32, H, W), dtype=torch.bfloat16, device=dy.device,
+                     memory_format=torch.channels_last)
+    L = lib()
+    nbytes = L.asr_conv7x7c32_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    check(L.asr_conv7x7c32_bwd_data_bf16(_p(dy), _p(weight), B, H, W, int(stride_h), _p(dx),
+                                         _p(ws), nbytes, _stream()), 'asr_conv7x7c32_bwd_data_bf16')
+    return dx
+
+
+def conv7x7c32_wgrad(x, dy, stride_h):
+    """asr_conv7x7c32_wgrad_bf16: x logical [B, 32, H, W], dy logical [B, 32, Ho, Wo]
+    (channels-last bf16) -> dw [32, 32, 7, 7] f32."""
+    x, B, C, H, W = _nhwc_bf16(x, 'x')
+    dy = _nhwc_bf16(dy, 'dy')[0]
+    dw = torch.empty((32, 32, 7, 7), dtype=torch.float32, device=x.device)
+    L = lib()
+    nbytes = L.asr_conv7x7c32_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(L.asr_conv7x7c32_wgrad_bf16(_p(x), _p(dy), B, H, W, int(stride_h), _p(dw), _p(ws),
+                                      nbytes, _stream()), 'asr_conv7x7c32_wgrad_bf16')
+    return dw

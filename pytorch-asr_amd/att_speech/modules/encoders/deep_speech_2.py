@@ -1,5 +1,6 @@
 """reference modules/encoders/deep_speech_2.py:14-160 — conv2d+BN+Hardtanh x2
 then bidirectional recurrent layers with summed directions."""
+import warnings
 from collections import OrderedDict
 
 import torch
@@ -22,6 +23,7 @@ class DeepSpeech2(BaseEncoder):
         import os
         self.conv_bf16 = os.environ.get('ASR_CONV_BF16', '1') != '0'
         self.fused_bn = os.environ.get('ASR_FUSED_BN', '1') != '0'
+        self.native_conv = os.environ.get('ASR_NATIVE_CONV', '1') != '0'
         if isinstance(rnn_type, str):
             rnn_type = {'LSTM': nn.LSTM, 'GRU': nn.GRU}[rnn_type.split('.')[-1]]
         self.makeConv(sample_batch, conv_strides, conv_kernel_sizes,
@@ -128,8 +130,16 @@ class DeepSpeech2(BaseEncoder):
             c1 = conv[0]
             x = run_conv(c1, features, with_bias=False, keep_bf16=True)
             x = bn_hardtanh(x, conv[1].batch_norm, conv[2], out_bf16=bf16, conv_bias=c1.bias)
-            x = bn_hardtanh(run_conv(c2, x, with_bias=False, keep_bf16=True),
-                            conv[4].batch_norm, conv[5], time_major=True, conv_bias=c2.bias)
+            from att_speech.modules.encoders import native_conv
+            if bf16 and self.native_conv and native_conv.supported(c2, x):
+                y2 = native_conv.conv7x7c32(x, c2)          # hand-written MFMA kernels
+            else:
+                if bf16 and self.native_conv and not getattr(self, '_warned_conv', False):
+                    self._warned_conv = True
+                    warnings.warn('DeepSpeech2: the second convolution is not the 32->32 7x7 '
+                                  'stride-(3,1) shape csrc/conv.hip is built for; using torch / MIOpen')
+                y2 = run_conv(c2, x, with_bias=False, keep_bf16=True)
+            x = bn_hardtanh(y2, conv[4].batch_norm, conv[5], time_major=True, conv_bias=c2.bias)
             return x.view(x.size(0), x.size(1), -1)                  # [T', B, C*F']
         if bf16:
             x = conv[5](conv[4](second_conv(conv[2](conv[1](conv[0](features))))))

@@ -1,0 +1,523 @@
+// 7x7, 32 -> 32 channel convolution of the DeepSpeech2 front-end (reference
+// att_speech/modules/encoders/deep_speech_2.py:60-73: Conv2d(32, 32, (7, 7), stride (3, 1)),
+// 97 % of the conv stack's flops) as hand-written MFMA kernels on channels-last bf16:
+// forward, input gradient, weight gradient.  fp32 accumulation, bias-free (the bias is folded
+// into the fused BatchNorm kernels, csrc/bnact.hip).
+//
+// Layouts: x [B, H, W, 32] bf16 (H = time, W = frequency), y [B, Ho, Wo, 32] bf16 with
+// Ho = (H - 7) / SH + 1, Wo = W - 6; w [32 co][32 ci][7][7] fp32 (nn.Conv2d's parameter).
+//
+// Common structure: a workgroup stages the input rows one block of output rows needs in LDS
+// (80-byte pixel stride: 64 B of channels + 16 B pad, so the 16-byte MFMA fragment reads of 16
+// consecutive pixels hit 16 disjoint bank groups), keeps its share of the weight fragments in
+// REGISTERS for its whole life, and feeds v_mfma_f32_32x32x16_bf16 with one ds_read_b128 per
+// MFMA whose address is a per-lane pixel base + an immediate (tap) offset.
+#include "common.h"
+#include "../../include/asr_amd.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int CH = 32;            // channels in and out
+constexpr int KS = 7;             // kernel size (both axes)
+constexpr int PIX = 80;           // bytes per pixel in LDS
+constexpr int KSTEPS = KS * KS * CH / 16;      // 98 MFMA k-steps of 16
+
+// ---- weight packing -------------------------------------------------------------------
+// forward: B[k][n], k = (kt * 7 + kf) * 32 + ci, n = co.
+// fragment of k-step s for lane l: B[16 s + 8 (l >> 5) + j][l & 31], j = 0..7
+__global__ void conv_pack_fwd_kernel(const float *w, __bf16 *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KSTEPS * 64 * 8) return;
+    const int j = i & 7, l = (i >> 3) & 63, s = i >> 9;
+    const int k = 16 * s + 8 * (l >> 5) + j, co = l & 31;
+    const int tap = k / CH, ci = k % CH, kt = tap / KS, kf = tap % KS;
+    out[i] = (__bf16)w[((co * CH + ci) * KS + kt) * KS + kf];
+}
+
+struct ConvFwdParams {
+    const __bf16 *x;
+    const __bf16 *wpack;
+    __bf16 *y;
+    int B, H, W, Ho, Wo, R;       // R output rows per workgroup (R * Wo <= 192)
+};
+
+// one k-half (49 k-steps) of the product for 3 M-tiles
+template <int SH, int KH>
+__device__ __forceinline__ void conv_fwd_half(const char *img, const unsigned (&pixbase)[3], int W,
+                                              const bf16x8 (&bf)[49], f32x16 (&acc)[3]) {
+#pragma unroll
+    for (int s = 0; s < 49; ++s) {
+        const int ks = 49 * KH + s;
+        const int kt = ks / 14, rem = ks % 14, kf = rem >> 1, cp = rem & 1;
+        const unsigned off = (unsigned)((kt * W + kf) * PIX + cp * 32);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(img + pixbase[i] + off);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[s], acc[i], 0, 0, 0);
+        }
+    }
+}
+
+template <int SH>
+__global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave & 1, mh = wave >> 1;
+    const int b = blockIdx.y, ho0 = blockIdx.x * p.R;
+    const int W = p.W, Wo = p.Wo, R = p.R;
+    const int in_rows = SH * (R - 1) + KS;
+    const int h0 = ho0 * SH;
+
+    // ---- weight fragments of this wave's k-half ------------------------------------------
+    bf16x8 bf[49];
+    {
+        const bf16x8 *src = reinterpret_cast<const bf16x8 *>(p.wpack) + (size_t)(49 * kh) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 49; ++s) bf[s] = src[(size_t)s * 64];
+    }
+    // ---- stage the input rows ----------------------------------------------------------------
+    {
+        const int chunks = in_rows * W * 4;                     // 16-byte chunks
+        const char *xb = reinterpret_cast<const char *>(p.x) + (size_t)b * p.H * W * 64;
+        for (int c = tid; c < chunks; c += 256) {
+            const int pix = c >> 2, part = c & 3;
+            const int row = pix / W;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (h0 + row < p.H)
+                v = *reinterpret_cast<const u32x4 *>(xb + ((size_t)(h0 + row) * W * 64 + (size_t)(pix - row * W) * 64 + part * 16));
+            *reinterpret_cast<u32x4 *>(smem + pix * PIX + part * 16) = v;
+        }
+    }
+    // ---- per-lane pixel bases of this wave's three M-tiles -------------------------------------
+    unsigned pixbase[3];
+    const int npix = R * Wo;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int m = 32 * (3 * mh + i) + (lane & 31);
+        if (m >= npix) m = npix - 1;                            // computed, never stored
+        const int r = m / Wo, wo = m - r * Wo;
+        pixbase[i] = (unsigned)(((r * SH) * W + wo) * PIX + (lane >> 5) * 16);
+    }
+    __syncthreads();
+    f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    if (kh == 0) conv_fwd_half<SH, 0>(smem, pixbase, W, bf, acc);
+    else conv_fwd_half<SH, 1>(smem, pixbase, W, bf, acc);
+    __syncthreads();                                            // image no longer needed
+
+    // ---- sum the two k-halves, convert, write [pixel][co] rows to LDS, copy out coalesced -----
+    float *part = reinterpret_cast<float *>(smem);              // [2 mh][3][16][64] fp32 = 24 KB
+    __bf16 *oimg = reinterpret_cast<__bf16 *>(smem + 2 * 3 * 16 * 64 * 4);   // [192][32] bf16
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) part[((mh * 3 + i) * 16 + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = acc[i][j] + part[((mh * 3 + i) * 16 + j) * 64 + lane];
+                const int m = 32 * (3 * mh + i) + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+                oimg[m * CH + (lane & 31)] = (__bf16)v;
+            }
+    }
+    __syncthreads();
+    {
+        const int rows_here = (p.Ho - ho0) < R ? (p.Ho - ho0) : R;
+        const int chunks = rows_here * Wo * 4;
+        char *yb = reinterpret_cast<char *>(p.y) + ((size_t)b * p.Ho + ho0) * Wo * 64;
+        for (int c = tid; c < chunks; c += 256)
+            *reinterpret_cast<u32x4 *>(yb + (size_t)c * 16) =
+                *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(oimg) + (size_t)c * 16);
+    }
+}
+
+
+// =========================================================================================
+// input gradient, stride (3, 1):  dx[b, 3q + r, w, ci] = sum_{j, kf, co} dy[b, q - j, w - kf, co]
+//                                                        * w[co, ci, r + 3j, kf]
+// i.e. per row class r = h mod 3 a stride-1 correlation of dy (zero-padded by 6 pixels left and
+// right and 2 rows above) with a J_r x 7 kernel, J_0 = 3, J_1 = J_2 = 2.
+// B[k][n]: k = (j, kf, co) -> 16-steps (j, kf, co half), n = ci.  Packed per class:
+// class 0: k-steps 0..41, class 1: 42..69, class 2: 70..97.
+// =========================================================================================
+__global__ void conv_pack_dgrad_kernel(const float *w, __bf16 *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KSTEPS * 64 * 8) return;
+    const int jj = i & 7, l = (i >> 3) & 63, s = i >> 9;
+    const int r = s < 42 ? 0 : (s < 70 ? 1 : 2);
+    const int sl = s - (r == 0 ? 0 : (r == 1 ? 42 : 70));           // k-step inside the class
+    const int j = sl / 14, rem = sl % 14, kf = rem >> 1, cp = rem & 1;
+    const int co = cp * 16 + 8 * (l >> 5) + jj, ci = l & 31, kt = r + 3 * j;
+    out[i] = (__bf16)w[((co * CH + ci) * KS + kt) * KS + kf];
+}
+
+struct ConvDgradParams {
+    const __bf16 *dy;
+    const __bf16 *wpack;
+    __bf16 *dx;
+    int B, H, W, Ho, Wo, Rq;      // Rq rows q per workgroup and class (Rq * W <= 192)
+};
+
+// NS k-steps starting at class-local step S0 (class row count J = 3 for r = 0, else 2)
+template <int NS, int S0>
+__device__ __forceinline__ void conv_dgrad_part(const char *img, const unsigned (&pixbase)[6], int Wp,
+                                                const bf16x8 *bf, f32x16 (&acc)[6]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int sl = S0 + s;
+        const int j = sl / 14, rem = sl % 14, kf = rem >> 1, cp = rem & 1;
+        const unsigned off = (unsigned)(((2 - j) * Wp + (6 - kf)) * PIX + cp * 32);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(img + pixbase[i] + off);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[s], acc[i], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradParams p) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, q0 = blockIdx.x * p.Rq;
+    const int W = p.W, Wo = p.Wo, Rq = p.Rq, Wp = Wo + 12;
+    // wave 0: class 0, k-steps 0..20; wave 1: class 0, 21..41; wave 2: class 1; wave 3: class 2
+    const int r = wave < 2 ? 0 : wave - 1;
+    bf16x8 bf[28];
+    {
+        const int first = wave == 0 ? 0 : (wave == 1 ? 21 : (wave == 2 ? 42 : 70));
+        const int n = wave < 2 ? 21 : 28;
+        const bf16x8 *src = reinterpret_cast<const bf16x8 *>(p.wpack) + (size_t)first * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 28; ++s) bf[s] = s < n ? src[(size_t)s * 64] : bf16x8{};
+    }
+    // ---- stage dy rows q0-2 .. q0+Rq-1, zero-padded by 6 pixels on both sides -------------------
+    {
+        const int rows = Rq + 2;
+        const int chunks = rows * Wp * 4;
+        const char *yb = reinterpret_cast<const char *>(p.dy) + (size_t)b * p.Ho * Wo * 64;
+        for (int c = tid; c < chunks; c += 256) {
+            const int pix = c >> 2, part = c & 3;
+            const int row = pix / Wp, col = pix - row * Wp;
+            const int ho = q0 - 2 + row, wo = col - 6;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ho >= 0 && ho < p.Ho && wo >= 0 && wo < Wo)
+                v = *reinterpret_cast<const u32x4 *>(yb + ((size_t)ho * Wo + wo) * 64 + part * 16);
+            *reinterpret_cast<u32x4 *>(smem + pix * PIX + part * 16) = v;
+        }
+    }
+    unsigned pixbase[6];
+    const int npix = Rq * W;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        int m = 32 * i + (lane & 31);
+        if (m >= npix) m = npix - 1;
+        const int q = m / W, w = m - q * W;
+        pixbase[i] = (unsigned)((q * Wp + w) * PIX + (lane >> 5) * 16);
+    }
+    __syncthreads();
+    f32x16 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    if (wave == 0) conv_dgrad_part<21, 0>(smem, pixbase, Wp, bf, acc);
+    else if (wave == 1) conv_dgrad_part<21, 21>(smem, pixbase, Wp, bf, acc);
+    else conv_dgrad_part<28, 0>(smem, pixbase, Wp, bf, acc);
+    __syncthreads();
+
+    // ---- epilogue: wave 1 -> wave 0 partial sum; [class][pixel][ci] bf16 image; coalesced rows ----
+    float *part = reinterpret_cast<float *>(smem);              // [6][16][64] fp32 = 24 KB
+    __bf16 *oimg = reinterpret_cast<__bf16 *>(smem + 6 * 16 * 64 * 4);       // [3][192][32] bf16
+    if (wave == 1) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) part[(i * 16 + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (wave != 1) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float v = acc[i][j];
+                if (wave == 0) v += part[(i * 16 + j) * 64 + lane];
+                const int m = 32 * i + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+                oimg[(r * 192 + m) * CH + (lane & 31)] = (__bf16)v;
+            }
+    }
+    __syncthreads();
+    {
+        // output rows h = 3 (q0 + q) + rc, one 64 W-byte row each
+        const int chunks_per_row = W * 4;
+        const int total = 3 * Rq * chunks_per_row;
+        char *xb = reinterpret_cast<char *>(p.dx) + (size_t)b * p.H * W * 64;
+        for (int c = tid; c < total; c += 256) {
+            const int rowi = c / chunks_per_row, within = c - rowi * chunks_per_row;
+            const int rc = rowi / Rq, q = rowi - rc * Rq;
+            const int h = 3 * (q0 + q) + rc;
+            if (h < p.H)
+                *reinterpret_cast<u32x4 *>(xb + (size_t)h * W * 64 + (size_t)within * 16) =
+                    *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(oimg) +
+                                                     ((size_t)(rc * 192 + q * W) * 64 + (size_t)within * 16));
+        }
+    }
+}
+
+
+// =========================================================================================
+// weight gradient, stride (3, 1):
+//   dw[co, ci, kt, kf] = sum_{b, ho, wo} dy[b, ho, wo, co] * x[b, 3 ho + kt, wo + kf, ci]
+// One 32 x 32 (co x ci) MFMA tile per tap, summed over pixels: the reduction index k of the
+// MFMA is the PIXEL, which is the slow index of both images in memory — both operands come
+// out of LDS through the transposing read ds_read_b64_tr_b16 (4 pixels x 16 channels per
+// 16-lane group, delivered channel-major).  A k-step = 16 consecutive wo of one output row
+// (rows padded with zero dy pixels up to a multiple of 16; the x pixels read beside them are
+// whatever follows in the image: finite, times zero).  Persistent workgroups walk chunks of
+// 8 output rows; wave w (of 7) accumulates tap row kt = w x all 7 kf in registers for its
+// whole life; partial sums per workgroup, then one reduction kernel.
+// =========================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char *addr) {
+    // two transposed 4 x 16 blocks: pixels k0..k0+3 and k0+4..k0+7 of the lane's k-half
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(addr));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(addr + 4 * PIX));
+    s16x8 v;
+    v.s0 = lo.x; v.s1 = lo.y; v.s2 = lo.z; v.s3 = lo.w;
+    v.s4 = hi.x; v.s5 = hi.y; v.s6 = hi.z; v.s7 = hi.w;
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int WGRAD_WGS = 256;    // persistent workgroups (one per CU: 7 waves each)
+constexpr int WGRAD_NT = 448;
+constexpr int NX_MAX = 8, ND_MAX = 3;          // 16-byte chunks a thread stages per chunk of rows
+
+struct ConvWgradParams {
+    const __bf16 *x, *dy;
+    float *partial;               // [workgroups][49][16][64]
+    int B, H, W, Ho, Wo, KW;      // KW = ceil(Wo / 16) k-steps per output row
+    int rows;                     // output rows per chunk
+};
+
+__global__ __launch_bounds__(WGRAD_NT) void conv7x7c32_wgrad_s3_kernel(ConvWgradParams p) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = p.W, Wo = p.Wo, KW = p.KW, Wd = 16 * KW, rows = p.rows;
+    const int xrows = 3 * (rows - 1) + KS;
+    char *ximg = smem;                                        // [xrows][W] pixels (+ tail pad)
+    char *dimg = smem + (size_t)(xrows * W + 24) * PIX;       // [rows][Wd] pixels
+    const int kt = wave;                                      // 7 waves: one tap row each
+    f32x16 acc[KS];
+#pragma unroll
+    for (int f = 0; f < KS; ++f)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[f][j] = 0.f;
+    // lane part of every transposed-read address: pixel 8 h + q, channels 16 chalf + 4 pp
+    const unsigned lane_off = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * PIX +
+                                         (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    for (int i = tid; i < 24 * PIX / 4; i += WGRAD_NT)        // tail pad: finite values
+        reinterpret_cast<unsigned *>(ximg + (size_t)xrows * W * PIX)[i] = 0u;
+    const int chunks_per_utt = (p.Ho + rows - 1) / rows;
+    const int nchunks = p.B * chunks_per_utt;
+    const int nx = xrows * W * 4, nd = rows * Wd * 4;
+    u32x4 sx[NX_MAX], sd[ND_MAX];
+    // global -> registers: x rows 3 ho0 .. 3 ho0 + xrows - 1 (zeros past H), dy rows ho0 .. (zero
+    // pixels up to Wd and past Ho)
+    auto fetch = [&](int c) {
+        const int b = c / chunks_per_utt, ho0 = (c - b * chunks_per_utt) * rows;
+        const char *xb = reinterpret_cast<const char *>(p.x) + (size_t)b * p.H * W * 64;
+        const char *yb = reinterpret_cast<const char *>(p.dy) + (size_t)b * p.Ho * Wo * 64;
+#pragma unroll
+        for (int k = 0; k < NX_MAX; ++k) {
+            const int i = tid + k * WGRAD_NT;
+            const int pix = i >> 2, part = i & 3, row = pix / W;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (i < nx && 3 * ho0 + row < p.H)
+                v = *reinterpret_cast<const u32x4 *>(xb + ((size_t)(3 * ho0) * W + pix) * 64 + part * 16);
+            sx[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < ND_MAX; ++k) {
+            const int i = tid + k * WGRAD_NT;
+            const int pix = i >> 2, part = i & 3, row = pix / Wd, wo = pix - row * Wd;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (i < nd && ho0 + row < p.Ho && wo < Wo)
+                v = *reinterpret_cast<const u32x4 *>(yb + ((size_t)(ho0 + row) * Wo + wo) * 64 + part * 16);
+            sd[k] = v;
+        }
+    };
+    auto stage = [&]() {                                      // registers -> LDS images
+#pragma unroll
+        for (int k = 0; k < NX_MAX; ++k) {
+            const int i = tid + k * WGRAD_NT;
+            if (i < nx) *reinterpret_cast<u32x4 *>(ximg + (i >> 2) * PIX + (i & 3) * 16) = sx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < ND_MAX; ++k) {
+            const int i = tid + k * WGRAD_NT;
+            if (i < nd) *reinterpret_cast<u32x4 *>(dimg + (i >> 2) * PIX + (i & 3) * 16) = sd[k];
+        }
+    };
+    int c = blockIdx.x;
+    if (c < nchunks) fetch(c);
+    __syncthreads();
+    if (c < nchunks) stage();
+    __syncthreads();
+    for (; c < nchunks; c += gridDim.x) {
+        const int next = c + gridDim.x;
+        if (next < nchunks) fetch(next);                      // in flight under this chunk's MFMAs
+        for (int r = 0; r < rows; ++r) {
+            for (int ks = 0; ks < KW; ++ks) {
+                const bf16x8 a = tr_frag(dimg + (size_t)(r * Wd + 16 * ks) * PIX + lane_off);
+                const char *xr = ximg + (size_t)((3 * r + kt) * W + 16 * ks) * PIX + lane_off;
+#pragma unroll
+                for (int f = 0; f < KS; ++f) {
+                    const bf16x8 bb = tr_frag(xr + f * PIX);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[f], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                      // every wave is done with the images
+        if (next < nchunks) stage();
+        __syncthreads();
+    }
+    // partial sums, raw accumulator order [tap][reg][lane]
+    float *out = p.partial + (size_t)blockIdx.x * 49 * 1024;
+#pragma unroll
+    for (int f = 0; f < KS; ++f)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) out[((kt * KS + f) * 16 + j) * 64 + lane] = acc[f][j];
+}
+
+// dw[co][ci][kt][kf] = sum over workgroups of partial[wg][tap][reg][lane]
+__global__ void conv_wgrad_reduce_kernel(const float *partial, int nwg, float *dw) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 49 * 1024) return;
+    float s = 0.f;
+    for (int g = 0; g < nwg; ++g) s += partial[(size_t)g * 49 * 1024 + e];
+    const int tap = e >> 10, j = (e >> 6) & 15, l = e & 63;
+    const int co = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5), ci = l & 31;
+    dw[(co * CH + ci) * 49 + tap] = s;
+}
+
+}  // namespace
+
+extern "C" int64_t asr_conv7x7c32_workspace_bytes(void) {
+    // two packed weight images (forward, input gradient) + the weight gradient's partial sums
+    return (int64_t)KSTEPS * 64 * 8 * 2 * 2 + (int64_t)WGRAD_WGS * 49 * 1024 * 4 + 256;
+}
+
+extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int H, int W,
+                                       int stride_h, void *y, void *workspace,
+                                       int64_t workspace_bytes, void *stream) {
+    if (B <= 0 || H < KS || W < KS) return ASR_EINVAL;
+    if (!x || !w || !y || !workspace || workspace_bytes < asr_conv7x7c32_workspace_bytes())
+        return ASR_EINVAL;
+    if (stride_h != 1 && stride_h != 3) return ASR_EUNSUPPORTED;
+    const int Ho = (H - KS) / stride_h + 1, Wo = W - KS + 1;
+    if (Wo > 48) return ASR_EUNSUPPORTED;
+    int R = 192 / Wo;
+    if (R > 16) R = 16;
+    const size_t img = (size_t)(stride_h * (R - 1) + KS) * W * PIX;
+    const size_t epi = (size_t)2 * 3 * 16 * 64 * 4 + (size_t)192 * CH * 2;
+    const size_t lds = img > epi ? img : epi;
+    if (lds > 80 * 1024) return ASR_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    __bf16 *wpack = (__bf16 *)workspace;
+    hipLaunchKernelGGL(conv_pack_fwd_kernel, dim3((KSTEPS * 64 * 8 + 255) / 256), dim3(256), 0, s, w, wpack);
+    ConvFwdParams p;
+    p.x = (const __bf16 *)x; p.wpack = wpack; p.y = (__bf16 *)y;
+    p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.R = R;
+    const dim3 grid((Ho + R - 1) / R, B);
+    void (*kern)(ConvFwdParams) = stride_h == 3 ? conv7x7c32_fwd_kernel<3> : conv7x7c32_fwd_kernel<1>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ASR_EUNSUPPORTED;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_conv7x7c32_bwd_data_bf16(const void *dy, const float *w, int B, int H, int W,
+                                            int stride_h, void *dx, void *workspace,
+                                            int64_t workspace_bytes, void *stream) {
+    if (B <= 0 || H < KS || W < KS) return ASR_EINVAL;
+    if (!dy || !w || !dx || !workspace || workspace_bytes < asr_conv7x7c32_workspace_bytes())
+        return ASR_EINVAL;
+    if (stride_h != 3) return ASR_EUNSUPPORTED;
+    const int Ho = (H - KS) / stride_h + 1, Wo = W - KS + 1;
+    if (W > 48) return ASR_EUNSUPPORTED;
+    int Rq = 192 / W;
+    if (Rq > 16) Rq = 16;
+    const size_t img = (size_t)(Rq + 2) * (Wo + 12) * PIX;
+    const size_t epi = (size_t)6 * 16 * 64 * 4 + (size_t)3 * 192 * CH * 2;
+    const size_t lds = img > epi ? img : epi;
+    if (lds > 80 * 1024) return ASR_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    __bf16 *wpack = (__bf16 *)workspace + (size_t)KSTEPS * 64 * 8;
+    hipLaunchKernelGGL(conv_pack_dgrad_kernel, dim3((KSTEPS * 64 * 8 + 255) / 256), dim3(256), 0, s, w, wpack);
+    ConvDgradParams p;
+    p.dy = (const __bf16 *)dy; p.wpack = wpack; p.dx = (__bf16 *)dx;
+    p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Rq = Rq;
+    const int nq = (H + 2) / 3;                                  // q = 0 .. ceil(H / 3) - 1
+    const dim3 grid((nq + Rq - 1) / Rq, B);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)conv7x7c32_dgrad_s3_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ASR_EUNSUPPORTED;
+    hipLaunchKernelGGL(conv7x7c32_dgrad_s3_kernel, grid, dim3(256), lds, s, p);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_conv7x7c32_wgrad_bf16(const void *x, const void *dy, int B, int H, int W,
+                                         int stride_h, float *dw, void *workspace,
+                                         int64_t workspace_bytes, void *stream) {
+    if (B <= 0 || H < KS || W < KS) return ASR_EINVAL;
+    if (!x || !dy || !dw || !workspace || workspace_bytes < asr_conv7x7c32_workspace_bytes())
+        return ASR_EINVAL;
+    if (stride_h != 3) return ASR_EUNSUPPORTED;
+    const int Ho = (H - KS) / stride_h + 1, Wo = W - KS + 1;
+    if (Wo > 48) return ASR_EUNSUPPORTED;
+    const int KW = (Wo + 15) / 16;
+    int rows = 8;                                  // output rows per chunk: as many as LDS and
+    size_t lds = 0;                                // the staging registers take
+    for (; rows >= 1; rows >>= 1) {
+        const int xrows = 3 * (rows - 1) + KS;
+        lds = (size_t)(xrows * W + 24) * PIX + (size_t)rows * 16 * KW * PIX;
+        if (lds <= 72 * 1024 && xrows * W * 4 <= NX_MAX * WGRAD_NT && rows * 16 * KW * 4 <= ND_MAX * WGRAD_NT)
+            break;
+    }
+    if (rows < 1) return ASR_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    ConvWgradParams p;
+    p.x = (const __bf16 *)x; p.dy = (const __bf16 *)dy;
+    p.partial = (float *)((char *)workspace + (size_t)KSTEPS * 64 * 8 * 2 * 2);
+    p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.KW = KW; p.rows = rows;
+    const int chunks = B * ((Ho + rows - 1) / rows);
+    const int nwg = chunks < WGRAD_WGS ? chunks : WGRAD_WGS;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)conv7x7c32_wgrad_s3_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ASR_EUNSUPPORTED;
+    hipLaunchKernelGGL(conv7x7c32_wgrad_s3_kernel, dim3(nwg), dim3(WGRAD_NT), lds, s, p);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((49 * 1024 + 255) / 256), dim3(256), 0, s,
+                       p.partial, nwg, dw);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}

@@ -1,0 +1,74 @@
+"""Hand-written 7x7 32->32 convolution kernels (csrc/conv.hip) against fp32 nn.Conv2d on the
+CPU — the op DeepSpeech2's second convolution runs (deep_speech_2.py:60-73)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(2, 58, 17, 3), (3, 31, 13, 1), (1, 1006, 17, 3), (5, 40, 23, 3), (2, 7, 7, 1)]
+
+
+def _inputs(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 32, H, W, generator=g)
+    w = torch.randn(32, 32, 7, 7, generator=g) * 0.05
+    return x, w
+
+
+@pytest.mark.parametrize('B,H,W,sh', CASES)
+def test_conv_forward_matches_conv2d(B, H, W, sh):
+    from att_speech import _native
+    x, w = _inputs(B, H, W, B * 100 + H)
+    dev = torch.device('cuda:0')
+    xb = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = _native.conv7x7c32_fwd(xb, w.to(dev), sh)
+    torch.cuda.synchronize()
+    # reference on the SAME bf16-rounded operands, fp32 arithmetic
+    want = F.conv2d(xb.float().cpu(), w.to(torch.bfloat16).float(), None, (sh, 1))
+    assert tuple(y.shape) == tuple(want.shape)
+    got = y.float().cpu()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-2 * scale     # bf16 output rounding: 2^-8
+    # the fp32 accumulation itself: compare before the output rounding where it is exact
+    rel = float(((got - want).abs() / (want.abs() + 1e-2 * scale)).max())
+    assert rel < 2e-2
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 58, 17), (1, 1006, 17), (3, 40, 23), (2, 9, 7), (2, 62, 17)])
+def test_conv_input_gradient_matches_conv2d(B, H, W):
+    from att_speech import _native
+    x, w = _inputs(B, H, W, B * 7 + H)
+    Ho, Wo = (H - 7) // 3 + 1, W - 6
+    g = torch.Generator().manual_seed(H)
+    dy = torch.randn(B, 32, Ho, Wo, generator=g)
+    dev = torch.device('cuda:0')
+    dyb = dy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dx = _native.conv7x7c32_bwd_data(dyb, w.to(dev), H, W, 3)
+    torch.cuda.synchronize()
+    want = torch.nn.grad.conv2d_input((B, 32, H, W), w.to(torch.bfloat16).float(),
+                                      dyb.float().cpu(), stride=(3, 1))
+    got = dx.float().cpu()
+    assert tuple(got.shape) == (B, 32, H, W)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-2 * scale
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 58, 17), (1, 1006, 17), (3, 40, 23), (2, 9, 7), (70, 31, 17),
+                                   (2, 64, 38)])
+def test_conv_weight_gradient_matches_conv2d(B, H, W):
+    from att_speech import _native
+    x, w = _inputs(B, H, W, B * 11 + H)
+    Ho, Wo = (H - 7) // 3 + 1, W - 6
+    g = torch.Generator().manual_seed(H + 1)
+    dy = torch.randn(B, 32, Ho, Wo, generator=g)
+    dev = torch.device('cuda:0')
+    xb = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dyb = dy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dw = _native.conv7x7c32_wgrad(xb, dyb, 3)
+    torch.cuda.synchronize()
+    want = torch.nn.grad.conv2d_weight(xb.float().cpu(), (32, 32, 7, 7), dyb.float().cpu(), stride=(3, 1))
+    got = dw.cpu()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-3 * scale      # fp32 accumulation of exact products
