@@ -307,6 +307,19 @@ int asr_conv7x7c32_wgrad_bf16(const void *x, const void *dy, int B, int H, int W
                               float *dw, void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
+ * The first convolution of the front-end, Conv2d(1, 32, (7, 7), stride (1, 2), padding (6, 0))
+ * (reference deep_speech_2.py:52-66) on the raw one-channel features:
+ *   x [B, T, F] f32, w [32, 1, 7, 7] f32, y [B, T + 6, (F - 7) / 2 + 1, 32] bf16 channels-last,
+ *   bias-free; wgrad: dw [32, 1, 7, 7] f32 from x and dy (y's layout).  The input needs no
+ *   gradient.  workspace: asr_conv1_7x7s2_workspace_bytes().
+ */
+int64_t asr_conv1_7x7s2_workspace_bytes(void);
+int asr_conv1_7x7s2_fwd(const float *x, const float *w, int B, int T, int F, void *y,
+                        void *workspace, int64_t workspace_bytes, void *stream);
+int asr_conv1_7x7s2_wgrad(const float *x, const void *dy, int B, int T, int F, float *dw,
+                          void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
  * One label step of the TCN / local-attention decoder for every live hypothesis
  * (replaces LocalAttention.forward, reference att_speech/modules/tcn.py:193-230, and the
  * context reduction of AttentionDecoderTCN.enc_step, :465-474).  Hypothesis h = u * beam + k

@@ -44,6 +44,9 @@ _SIGNATURES = {
     'asr_conv7x7c32_fwd_bf16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     'asr_conv7x7c32_bwd_data_bf16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     'asr_conv7x7c32_wgrad_bf16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    'asr_conv1_7x7s2_workspace_bytes': (_i64, []),
+    'asr_conv1_7x7s2_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    'asr_conv1_7x7s2_wgrad': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
     'asr_tcn_attention_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                         _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_beam_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f,
@@ -569,4 +572,35 @@ def conv7x7c32_wgrad(x, dy, stride_h):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     check(L.asr_conv7x7c32_wgrad_bf16(_p(x), _p(dy), B, H, W, int(stride_h), _p(dw), _p(ws),
                                       nbytes, _stream()), 'asr_conv7x7c32_wgrad_bf16')
+    return dw
+
+
+def conv1_fwd(x, weight):
+    """asr_conv1_7x7s2_fwd: x [B, T, F] f32, weight [32, 1, 7, 7] f32 -> y logical
+    [B, 32, T + 6, (F - 7) // 2 + 1] channels-last bf16."""
+    x = _dev(x, torch.float32, 'x')
+    weight = _dev(weight, torch.float32, 'weight')
+    B, T, F = x.shape
+    y = torch.empty((B, 32, T + 6, (F - 7) // 2 + 1), dtype=torch.bfloat16, device=x.device,
+                    memory_format=torch.channels_last)
+    L = lib()
+    nbytes = L.asr_conv1_7x7s2_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(L.asr_conv1_7x7s2_fwd(_p(x), _p(weight), B, T, F, _p(y), _p(ws), nbytes, _stream()),
+          'asr_conv1_7x7s2_fwd')
+    return y
+
+
+def conv1_wgrad(x, dy):
+    """asr_conv1_7x7s2_wgrad: x [B, T, F] f32, dy logical [B, 32, To, Fo] channels-last bf16
+    -> dw [32, 1, 7, 7] f32."""
+    x = _dev(x, torch.float32, 'x')
+    dy = _nhwc_bf16(dy, 'dy')[0]
+    B, T, F = x.shape
+    dw = torch.empty((32, 1, 7, 7), dtype=torch.float32, device=x.device)
+    L = lib()
+    nbytes = L.asr_conv1_7x7s2_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(L.asr_conv1_7x7s2_wgrad(_p(x), _p(dy), B, T, F, _p(dw), _p(ws), nbytes, _stream()),
+          'asr_conv1_7x7s2_wgrad')
     return dw

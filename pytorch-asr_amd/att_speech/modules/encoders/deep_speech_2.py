@@ -127,10 +127,13 @@ class DeepSpeech2(BaseEncoder):
             # BatchNorm kernels (no broadcast add, no full-tensor reduction for the
             # bias gradient)
             from att_speech.modules.encoders.native_bn import bn_hardtanh
-            c1 = conv[0]
-            x = run_conv(c1, features, with_bias=False, keep_bf16=True)
-            x = bn_hardtanh(x, conv[1].batch_norm, conv[2], out_bf16=bf16, conv_bias=c1.bias)
             from att_speech.modules.encoders import native_conv
+            c1 = conv[0]
+            if bf16 and self.native_conv and native_conv.first_supported(c1, features):
+                x = native_conv.conv1(features, c1)          # hand-written MFMA kernels
+            else:
+                x = run_conv(c1, features, with_bias=False, keep_bf16=True)
+            x = bn_hardtanh(x, conv[1].batch_norm, conv[2], out_bf16=bf16, conv_bias=c1.bias)
             if bf16 and self.native_conv and native_conv.supported(c2, x):
                 y2 = native_conv.conv7x7c32(x, c2)          # hand-written MFMA kernels
             else:

@@ -36,6 +36,36 @@ class Conv7x7C32Function(torch.autograd.Function):
         return dx, dw
 
 
+def first_supported(conv, x):
+    """Conv2d(1, 32, (7, 7), stride (1, 2), padding (6, 0)) on [B, 1, T, F] features"""
+    return (x.is_cuda and isinstance(conv, torch.nn.Conv2d) and conv.in_channels == 1
+            and conv.out_channels == 32 and tuple(conv.kernel_size) == (7, 7)
+            and tuple(conv.stride) == (1, 2) and tuple(conv.padding) == (6, 0)
+            and tuple(conv.dilation) == (1, 1) and x.dim() == 4 and x.size(1) == 1
+            and 7 <= x.size(3) and (x.size(3) - 7) // 2 + 1 <= 64)
+
+
+class Conv1Function(torch.autograd.Function):
+    """features [B, T, F] f32 -> [B, 32, T + 6, Fo] channels-last bf16; the features need no
+    gradient, the weight gradient is asr_conv1_7x7s2_wgrad"""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.float().contiguous()
+        ctx.save_for_backward(x, weight)
+        return _native.conv1_fwd(x, weight.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        return None, (_native.conv1_wgrad(x, dy) if ctx.needs_input_grad[1] else None)
+
+
+def conv1(features, conv):
+    """features logical [B, 1, T, F] (any strides) -> conv(features) without the bias"""
+    return Conv1Function.apply(features[:, 0], conv.weight)
+
+
 def conv7x7c32(x, conv):
     """y = conv(x) without the bias: logical [B, 32, Ho, Wo] bf16, channels-last memory"""
     return Conv7x7C32Function.apply(x, conv.weight)

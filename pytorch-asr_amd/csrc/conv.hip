@@ -407,15 +407,196 @@ __global__ __launch_bounds__(WGRAD_NT) void conv7x7c32_wgrad_s3_kernel(ConvWgrad
         for (int j = 0; j < 16; ++j) out[((kt * KS + f) * 16 + j) * 64 + lane] = acc[f][j];
 }
 
-// dw[co][ci][kt][kf] = sum over workgroups of partial[wg][tap][reg][lane]
-__global__ void conv_wgrad_reduce_kernel(const float *partial, int nwg, float *dw) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 49 * 1024) return;
+// sum of `nparts` partial images of `n` floats: 64 consecutive elements per 256-thread block,
+// the partials split over the block's waves (coalesced 256-byte reads)
+__device__ __forceinline__ float partial_sum(const float *partial, int nparts, int n, float *lds) {
+    const int el = threadIdx.x & 63, part = threadIdx.x >> 6, ways = blockDim.x >> 6;
+    const int e = blockIdx.x * 64 + el;
     float s = 0.f;
-    for (int g = 0; g < nwg; ++g) s += partial[(size_t)g * 49 * 1024 + e];
+    if (e < n)
+        for (int g = part; g < nparts; g += ways) s += partial[(size_t)g * n + e];
+    lds[part * 64 + el] = s;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < ways; ++w) t += lds[w * 64 + el];
+    return t;
+}
+
+// dw[co][ci][kt][kf] = sum over workgroups of partial[wg][tap][reg][lane]
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float *partial, int nwg, float *dw) {
+    __shared__ float lds4[1024];
+    const float s = partial_sum(partial, nwg, 49 * 1024, lds4);
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (threadIdx.x >= 64 || e >= 49 * 1024) return;
     const int tap = e >> 10, j = (e >> 6) & 15, l = e & 63;
     const int co = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5), ci = l & 31;
     dw[(co * CH + ci) * 49 + tap] = s;
+}
+
+
+// =========================================================================================
+// First convolution of the front-end: Conv2d(1, 32, (7, 7), stride (1, 2), padding (6, 0))
+// (reference deep_speech_2.py:52-66) on the raw features x [B, T, F] fp32 ->
+// y [B, To = T + 6, Fo = (F - 7) / 2 + 1, 32] bf16 channels-last.  49 taps padded to K = 64:
+// k = kt * 8 + kf (kf = 7 and kt = 7 carry zero weights).  A workgroup turns the input rows of
+// 16 output rows into a WINDOW image in LDS — for every (row, fo) the 8 consecutive samples
+// x[row][2 fo .. 2 fo + 7] as bf16, 16 bytes — so an MFMA A-fragment (one tap row of one
+// pixel) is one aligned ds_read_b128 and, for the weight gradient, a 4-tap group of one pixel
+// is one aligned 8-byte piece for ds_read_b64_tr_b16.  HBM-bound: the 32-channel bf16 output
+// (forward) / gradient (weight gradient) dominates, the MFMA work is 4 k-steps per 32 pixels.
+// =========================================================================================
+constexpr int C1_ROWS = 16;       // output rows per chunk
+
+__global__ void conv1_pack_kernel(const float *w, __bf16 *out) {      // [4 k-steps][64][8]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * 64 * 8) return;
+    const int j = i & 7, l = (i >> 3) & 63, s = i >> 9;
+    const int kt = 2 * s + (l >> 5), kf = j, co = l & 31;
+    out[i] = (kt < KS && kf < KS) ? (__bf16)w[(co * KS + kt) * KS + kf] : (__bf16)0.f;
+}
+
+struct Conv1Params {
+    const float *x;               // [B, T, F]
+    const __bf16 *wpack;
+    __bf16 *y;                    // forward: out; weight gradient: dy
+    float *partial;
+    int B, T, F, To, Fo;
+};
+
+// window image of input rows t0-6 .. t0-6+nrows-1: [nrows][Fo] x 8 bf16
+__device__ __forceinline__ void conv1_stage_windows(const Conv1Params &p, int b, int t0, int nrows,
+                                                    char *wimg, int tid, int nt) {
+    const float *xb = p.x + (size_t)b * p.T * p.F;
+    for (int i = tid; i < nrows * p.Fo; i += nt) {
+        const int row = i / p.Fo, fo = i - row * p.Fo, t = t0 - 6 + row;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = 2 * fo + j;
+            v[j] = (t >= 0 && t < p.T && f < p.F) ? (__bf16)xb[(size_t)t * p.F + f] : (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8 *>(wimg + (size_t)i * 16) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Params p) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, t0 = blockIdx.x * C1_ROWS, Fo = p.Fo;
+    const int npix = C1_ROWS * Fo, ntiles = (npix + 31) >> 5;
+    char *wimg = smem;                                         // [C1_ROWS + 8][Fo] windows
+    __bf16 *oimg = reinterpret_cast<__bf16 *>(smem + (size_t)(C1_ROWS + 8) * Fo * 16);   // [ntiles*32][32]
+    bf16x8 bf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bf[s] = reinterpret_cast<const bf16x8 *>(p.wpack)[s * 64 + lane];
+    conv1_stage_windows(p, b, t0, C1_ROWS + 8, wimg, tid, 256);   // rows past the 7th tap: finite
+    __syncthreads();
+    for (int tile = wave; tile < ntiles; tile += 4) {
+        int m = 32 * tile + (lane & 31);
+        if (m >= npix) m = npix - 1;
+        const int r = m / Fo, fo = m - r * Fo;
+        const char *base = wimg + (size_t)((r + (lane >> 5)) * Fo + fo) * 16;
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(base + (size_t)(2 * s * Fo) * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int mm = 32 * tile + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+            oimg[mm * CH + (lane & 31)] = (__bf16)acc[j];
+        }
+    }
+    __syncthreads();
+    const int rows_here = (p.To - t0) < C1_ROWS ? (p.To - t0) : C1_ROWS;
+    char *yb = reinterpret_cast<char *>(p.y) + ((size_t)b * p.To + t0) * Fo * 64;
+    for (int c = tid; c < rows_here * Fo * 4; c += 256)
+        *reinterpret_cast<u32x4 *>(yb + (size_t)c * 16) =
+            *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(oimg) + (size_t)c * 16);
+}
+
+// weight gradient: dw[co][kt][kf] = sum_{b,t,fo} dy[b,t,fo,co] * x[b, t + kt - 6, 2 fo + kf]
+// M = co, N = 64 taps (two tiles), K = the 16 * Fo pixels of a chunk in flattened order.
+constexpr int C1_WGS = 1024;     // 4 workgroups per CU: the chunks' load latencies overlap
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Params p) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Fo = p.Fo, npix = C1_ROWS * Fo, nks = npix >> 4;            // 16 | npix
+    char *wimg = smem;                                                    // [C1_ROWS + 8][Fo] windows
+    char *dimg = smem + (size_t)(C1_ROWS + 8) * Fo * 16;                  // [npix] pixels x 80 B
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    const int h = lane >> 5, q = (lane & 15) >> 2, pp = lane & 3, chalf = (lane >> 4) & 1;
+    const unsigned a_off = (unsigned)((8 * h + q) * PIX + (16 * chalf + 4 * pp) * 2);
+    // B: taps 32 nt + 16 chalf + 4 pp .. + 3  ->  kt = 4 nt + 2 chalf + (pp >> 1), kf = 4 (pp & 1)
+    const int ktl = 2 * chalf + (pp >> 1);
+    const unsigned b_lane = (unsigned)(8 * (pp & 1));
+    const int chunks_per_utt = (p.To + C1_ROWS - 1) / C1_ROWS;
+    const int nchunks = p.B * chunks_per_utt;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int b = c / chunks_per_utt, t0 = (c - b * chunks_per_utt) * C1_ROWS;
+        __syncthreads();
+        conv1_stage_windows(p, b, t0, C1_ROWS + 8, wimg, tid, 256);
+        {
+            const char *yb = reinterpret_cast<const char *>(p.y) + ((size_t)b * p.To + t0) * Fo * 64;
+            const int rows_here = (p.To - t0) < C1_ROWS ? (p.To - t0) : C1_ROWS;
+            for (int i = tid; i < npix * 4; i += 256) {
+                const int pix = i >> 2, part = i & 3;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (pix < rows_here * Fo) v = *reinterpret_cast<const u32x4 *>(yb + (size_t)pix * 64 + part * 16);
+                *reinterpret_cast<u32x4 *>(dimg + pix * PIX + part * 16) = v;
+            }
+        }
+        __syncthreads();
+        for (int ks = wave; ks < nks; ks += 4) {
+            const bf16x8 a = tr_frag(dimg + (size_t)(16 * ks) * PIX + a_off);
+            // window addresses of this lane's two pixel quartets
+            const int p0 = 16 * ks + 8 * h + q, p1 = p0 + 4;
+            const int r0 = p0 / Fo, f0 = p0 - r0 * Fo, r1 = p1 / Fo, f1 = p1 - r1 * Fo;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int kt = 4 * nt + ktl;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4 *)(wimg + (size_t)((r0 + kt) * Fo + f0) * 16 + b_lane));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4 *)(wimg + (size_t)((r1 + kt) * Fo + f1) * 16 + b_lane));
+                s16x8 v;
+                v.s0 = lo.x; v.s1 = lo.y; v.s2 = lo.z; v.s3 = lo.w;
+                v.s4 = hi.x; v.s5 = hi.y; v.s6 = hi.z; v.s7 = hi.w;
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, v), acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    // the four waves' sums -> one partial image per workgroup
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);                         // [4][2][16][64]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[((wave * 2 + nt) * 16 + j) * 64 + lane] = acc[nt][j];
+    __syncthreads();
+    float *out = p.partial + (size_t)blockIdx.x * 2 * 1024;
+    for (int e = tid; e < 2 * 1024; e += 256)
+        out[e] = red[e] + red[2048 + e] + red[4096 + e] + red[6144 + e];
+}
+
+__global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *partial, int nparts, float *dw) {
+    __shared__ float lds4[1024];
+    const float s = partial_sum(partial, nparts, 2 * 1024, lds4);
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (threadIdx.x >= 64) return;
+    const int nt = e >> 10, j = (e >> 6) & 15, l = e & 63;
+    const int co = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5), tap = 32 * nt + (l & 31);
+    const int kt = tap >> 3, kf = tap & 7;
+    if (kt < KS && kf < KS) dw[(co * KS + kt) * KS + kf] = s;
 }
 
 }  // namespace
@@ -517,7 +698,62 @@ extern "C" int asr_conv7x7c32_wgrad_bf16(const void *x, const void *dy, int B, i
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ASR_EUNSUPPORTED;
     hipLaunchKernelGGL(conv7x7c32_wgrad_s3_kernel, dim3(nwg), dim3(WGRAD_NT), lds, s, p);
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((49 * 1024 + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(49 * 1024 / 64), dim3(256), 0, s,
                        p.partial, nwg, dw);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int64_t asr_conv1_7x7s2_workspace_bytes(void) {
+    return 4 * 64 * 8 * 2 + (int64_t)C1_WGS * 2 * 1024 * 4 + 256;
+}
+
+static int conv1_shapes(int B, int T, int F, int *To, int *Fo) {
+    if (B <= 0 || T <= 0 || F < KS) return ASR_EINVAL;
+    *To = T + 2 * 6 - KS + 1;
+    *Fo = (F - KS) / 2 + 1;
+    if (*Fo > 64) return ASR_EUNSUPPORTED;
+    return ASR_OK;
+}
+
+extern "C" int asr_conv1_7x7s2_fwd(const float *x, const float *w, int B, int T, int F, void *y,
+                                   void *workspace, int64_t workspace_bytes, void *stream) {
+    int To, Fo;
+    const int rc = conv1_shapes(B, T, F, &To, &Fo);
+    if (rc != ASR_OK) return rc;
+    if (!x || !w || !y || !workspace || workspace_bytes < asr_conv1_7x7s2_workspace_bytes())
+        return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    __bf16 *wpack = (__bf16 *)workspace;
+    hipLaunchKernelGGL(conv1_pack_kernel, dim3(8), dim3(256), 0, s, w, wpack);
+    Conv1Params p;
+    p.x = x; p.wpack = wpack; p.y = (__bf16 *)y; p.partial = nullptr;
+    p.B = B; p.T = T; p.F = F; p.To = To; p.Fo = Fo;
+    const int ntiles = (C1_ROWS * Fo + 31) / 32;
+    const size_t lds = (size_t)(C1_ROWS + 8) * Fo * 16 + (size_t)ntiles * 32 * CH * 2;
+    if (lds > 64 * 1024) return ASR_EUNSUPPORTED;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((To + C1_ROWS - 1) / C1_ROWS, B), dim3(256), lds, s, p);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_conv1_7x7s2_wgrad(const float *x, const void *dy, int B, int T, int F,
+                                     float *dw, void *workspace, int64_t workspace_bytes,
+                                     void *stream) {
+    int To, Fo;
+    const int rc = conv1_shapes(B, T, F, &To, &Fo);
+    if (rc != ASR_OK) return rc;
+    if (!x || !dy || !dw || !workspace || workspace_bytes < asr_conv1_7x7s2_workspace_bytes())
+        return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    Conv1Params p;
+    p.x = x; p.wpack = nullptr; p.y = (__bf16 *)const_cast<void *>(dy);
+    p.partial = (float *)((char *)workspace + 4 * 64 * 8 * 2);
+    p.B = B; p.T = T; p.F = F; p.To = To; p.Fo = Fo;
+    size_t lds = (size_t)(C1_ROWS + 8) * Fo * 16 + (size_t)C1_ROWS * Fo * PIX;
+    if (lds < 4 * 2 * 1024 * 4) lds = 4 * 2 * 1024 * 4;            // the final four-wave sum
+    if (lds > 64 * 1024) return ASR_EUNSUPPORTED;
+    const int chunks = B * ((To + C1_ROWS - 1) / C1_ROWS);
+    const int nwg = chunks < C1_WGS ? chunks : C1_WGS;
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(nwg), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(2 * 1024 / 64), dim3(1024), 0, s, p.partial, nwg, dw);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }

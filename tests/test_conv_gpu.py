@@ -72,3 +72,30 @@ def test_conv_weight_gradient_matches_conv2d(B, H, W):
     got = dw.cpu()
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 2e-3 * scale      # fp32 accumulation of exact products
+
+
+@pytest.mark.parametrize('B,T,F', [(2, 50, 40), (1, 1000, 40), (3, 33, 81), (2, 5, 9)])
+def test_first_convolution_forward_and_weight_gradient(B, T, F):
+    """Conv2d(1, 32, 7x7, stride (1, 2), padding (6, 0)) on the raw features"""
+    from att_speech import _native
+    g = torch.Generator().manual_seed(B * 31 + T)
+    x = torch.randn(B, T, F, generator=g)
+    w = torch.randn(32, 1, 7, 7, generator=g) * 0.1
+    dev = torch.device('cuda:0')
+    y = _native.conv1_fwd(x.to(dev), w.to(dev))
+    xr = x.to(torch.bfloat16).float()[:, None]                       # operands as the kernel rounds them
+    want = F_conv(xr, w.to(torch.bfloat16).float())
+    got = y.float().cpu()
+    assert tuple(got.shape) == tuple(want.shape)
+    assert float((got - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    dy = torch.randn(want.shape, generator=g)
+    dyb = dy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dw = _native.conv1_wgrad(x.to(dev), dyb)
+    torch.cuda.synchronize()
+    want_dw = torch.nn.grad.conv2d_weight(xr, (32, 1, 7, 7), dyb.float().cpu(), stride=(1, 2),
+                                          padding=(6, 0))
+    assert float((dw.cpu() - want_dw).abs().max()) <= 2e-3 * float(want_dw.abs().max())
+
+
+def F_conv(x, w):
+    return F.conv2d(x, w, None, (1, 2), (6, 0))
