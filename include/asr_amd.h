@@ -286,6 +286,13 @@ int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_bias, int B,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
+ * out[e] = sum over g < G of in[g * n + e] (n % 4 == 0): the sum of the partial products of a
+ * weight-gradient GEMM split over chunks of frames (torch's strided reduction reads at
+ * 1.4 TB/s here).
+ */
+int asr_sum_leading_f32(const float *in, int G, int64_t n, float *out, void *stream);
+
+/*
  * The 7x7, 32 -> 32 channel convolution of the DeepSpeech2 front-end (reference
  * att_speech/modules/encoders/deep_speech_2.py:60-73, Conv2d(32, 32, (7, 7), stride
  * (stride_h, 1)), stride_h in {1, 3}) on channels-last bf16 with fp32 accumulation, bias-free

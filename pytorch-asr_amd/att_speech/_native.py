@@ -47,6 +47,7 @@ _SIGNATURES = {
     'asr_conv1_7x7s2_workspace_bytes': (_i64, []),
     'asr_conv1_7x7s2_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
     'asr_conv1_7x7s2_wgrad': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    'asr_sum_leading_f32': (_i, [_vp, _i, _i64, _vp, _vp]),
     'asr_tcn_attention_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                         _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_beam_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f,
@@ -604,3 +605,14 @@ def conv1_wgrad(x, dy):
     check(L.asr_conv1_7x7s2_wgrad(_p(x), _p(dy), B, T, F, _p(dw), _p(ws), nbytes, _stream()),
           'asr_conv1_7x7s2_wgrad')
     return dw
+
+
+def sum_leading(t):
+    """asr_sum_leading_f32: t [G, ...] f32 contiguous on the GPU -> t.sum(0)"""
+    if not t.is_cuda or t.dtype != torch.float32 or (t[0].numel() & 3):
+        return t.sum(0)
+    t = t.contiguous()
+    out = torch.empty(t.shape[1:], dtype=torch.float32, device=t.device)
+    check(lib().asr_sum_leading_f32(_p(t), t.shape[0], t[0].numel(), _p(out), _stream()),
+          'asr_sum_leading_f32')
+    return out

@@ -69,7 +69,7 @@ class _FrameProjection(torch.autograd.Function):
         if weight.size(0) > 256:            # wide outputs fill the chip as one product
             dweight = dy_r.t().mm(x_r)
         else:
-            dweight = torch.bmm(dy_c.transpose(1, 2), x_r.view(g, rows // g, -1)).sum(0)
+            dweight = _native.sum_leading(torch.bmm(dy_c.transpose(1, 2), x_r.view(g, rows // g, -1)))
         dbias = dy_c.sum(1).sum(0) if ctx.with_bias else None
         return dy_r.matmul(weight).view_as(x), dweight, dbias
 

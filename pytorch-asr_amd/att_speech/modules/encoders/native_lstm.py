@@ -80,12 +80,13 @@ class BiLSTMFunction(torch.autograd.Function):
         # zero-padded bf16 plane), the reverse one frame ahead (frames 2..T+1).
         TB = T * B
         g1, g2 = _chunks(TB, 16), _chunks(TB, 32)
-        dw_ih = _bmm_f32(dg2.view(g1, TB // g1, 8 * H).transpose(1, 2),
-                         xb.view(g1, TB // g1, F)).sum(0)                 # [2*4H, F]
+        dw_ih = _native.sum_leading(_bmm_f32(dg2.view(g1, TB // g1, 8 * H).transpose(1, 2),
+                                             xb.view(g1, TB // g1, F)))   # [2*4H, F]
         dgd = dgb.view(g2, TB // g2, 2, 4 * H)
-        dw_hh = [_bmm_f32(dgd[:, :, d].transpose(1, 2),
-                          (ybf[0, 0:T] if d == 0 else ybf[1, 2:T + 2]).reshape(g2, TB // g2, H)
-                          ).sum(0) for d in range(2)]
+        dw_hh = [_native.sum_leading(_bmm_f32(
+            dgd[:, :, d].transpose(1, 2),
+            (ybf[0, 0:T] if d == 0 else ybf[1, 2:T + 2]).reshape(g2, TB // g2, H)))
+            for d in range(2)]
         return dx, None, dw_ih[:4 * H], dw_hh[0], dw_ih[4 * H:], dw_hh[1], None
 
 

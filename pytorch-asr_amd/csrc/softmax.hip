@@ -227,3 +227,28 @@ extern "C" int asr_argmax_rows_f32(const float *x, int64_t rows, int C,
 #undef CALL
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
+
+
+// out[e] = sum_g in[g][e] for G stacked fp32 images of n elements (n % 4 == 0): the partial
+// products of the chunked weight-gradient GEMMs (att_speech/modules/encoders/native_lstm.py).
+// One float4 per thread per image, all G loads of a thread independent: HBM-bound.
+namespace {
+__global__ __launch_bounds__(256) void sum_leading_kernel(const float4 *in, int G, int64_t n4, float4 *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = in[i];
+    for (int g = 1; g < G; ++g) {
+        const float4 v = in[(int64_t)g * n4 + i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    out[i] = a;
+}
+}  // namespace
+
+extern "C" int asr_sum_leading_f32(const float *in, int G, int64_t n, float *out, void *stream) {
+    if (!in || !out || G <= 0 || n <= 0 || (n & 3)) return ASR_EINVAL;
+    const int64_t n4 = n >> 2;
+    hipLaunchKernelGGL(sum_leading_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4 *)in, G, n4, (float4 *)out);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
