@@ -259,6 +259,9 @@ int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf1
  * produced x, added on the fly (x is then the bias-free convolution), so the
  * framework needs neither the broadcast add nor the full-tensor reduction for its
  * gradient; the backward returns that gradient in dconv_bias (may be null).
+ * chan_sums (or null): [2][C] doubles, (sum x, sum x^2) per channel of the bias-free input,
+ * as the convolution kernels below emit them from their epilogues — the statistics pass
+ * over x is then skipped (training only).
  * workspace: asr_bn_act_workspace_bytes(C).
  */
 int64_t asr_bn_act_workspace_bytes(int C);
@@ -269,6 +272,7 @@ int asr_bn_act_fwd_f32(const void *x, int x_bf16, const float *conv_bias, int B,
                        int training, float momentum, float eps, float lo, float hi,
                        void *out, int out_bf16, int out_time_major,
                        float *save_mean, float *save_invstd,
+                       const double *chan_sums,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
@@ -301,11 +305,14 @@ int asr_sum_leading_f32(const float *in, int G, int64_t n, float *out, void *str
  *   Ho = (H - 7) / stride_h + 1, Wo = W - 6 (<= 48).
  * fwd: y = conv(x, w);  bwd_data: dx = conv_transpose(dy, w) [B, H, W, 32] bf16;
  * wgrad: dw [32, 32, 7, 7] f32 = sum over the batch of dy (x) x (overwritten).
+ * chan_sums (or null): [2][32] doubles, per output channel the sum and the sum of squares of
+ * the bf16 outputs — what the following BatchNorm needs (asr_bn_act_fwd_f32).
  * workspace: asr_conv7x7c32_workspace_bytes() (packed weight fragments / partial sums).
  */
 int64_t asr_conv7x7c32_workspace_bytes(void);
 int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int H, int W, int stride_h,
-                            void *y, void *workspace, int64_t workspace_bytes, void *stream);
+                            void *y, double *chan_sums, void *workspace, int64_t workspace_bytes,
+                            void *stream);
 /* stride_h = 3 only (the shape the encoder uses); H, W are the INPUT's (dx's) extents */
 int asr_conv7x7c32_bwd_data_bf16(const void *dy, const float *w, int B, int H, int W,
                                  int stride_h, void *dx, void *workspace,
@@ -322,7 +329,7 @@ int asr_conv7x7c32_wgrad_bf16(const void *x, const void *dy, int B, int H, int W
  */
 int64_t asr_conv1_7x7s2_workspace_bytes(void);
 int asr_conv1_7x7s2_fwd(const float *x, const float *w, int B, int T, int F, void *y,
-                        void *workspace, int64_t workspace_bytes, void *stream);
+                        double *chan_sums, void *workspace, int64_t workspace_bytes, void *stream);
 int asr_conv1_7x7s2_wgrad(const float *x, const void *dy, int B, int T, int F, float *dw,
                           void *workspace, int64_t workspace_bytes, void *stream);
 

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -41,11 +41,11 @@ _SIGNATURES = {
     'asr_sub_rowmax_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_argmax_rows_f32': (_i, [_vp, _i64, _i, _vp, _vp]),
     'asr_conv7x7c32_workspace_bytes': (_i64, []),
-    'asr_conv7x7c32_fwd_bf16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    'asr_conv7x7c32_fwd_bf16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_conv7x7c32_bwd_data_bf16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     'asr_conv7x7c32_wgrad_bf16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     'asr_conv1_7x7s2_workspace_bytes': (_i64, []),
-    'asr_conv1_7x7s2_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    'asr_conv1_7x7s2_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_conv1_7x7s2_wgrad': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
     'asr_sum_leading_f32': (_i, [_vp, _i, _i64, _vp, _vp]),
     'asr_tcn_attention_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
@@ -63,7 +63,7 @@ _SIGNATURES = {
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'asr_bn_act_workspace_bytes': (_i64, [_i]),
     'asr_bn_act_fwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
-                                _vp, _i, _i, _vp, _vp, _vp, _i64, _vp]),
+                                _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_bn_act_bwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
@@ -418,7 +418,7 @@ def _nchw_or_nhwc(t, name, dtype):
 
 
 def bn_act_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, lo, hi,
-               out_bf16=False, time_major=False, conv_bias=None):
+               out_bf16=False, time_major=False, conv_bias=None, chan_sums=None):
     """asr_bn_act_fwd_f32 on x [B,C,H,W] f32 (NCHW or channels_last storage) or bf16
     (channels_last) ->
     (out, save_mean [C], save_invstd [C]); out is [B,C,H,W] in x's memory format or,
@@ -447,7 +447,8 @@ def bn_act_fwd(x, gamma, beta, running_mean, running_var, training, momentum, ep
     check(L.asr_bn_act_fwd_f32(_p(x), int(x.dtype == torch.bfloat16), _p(conv_bias), B, C, H, W, _p(gamma), _p(beta), _p(running_mean),
                                _p(running_var), int(cl), int(bool(training)), float(momentum),
                                float(eps), float(lo), float(hi), _p(out), int(out_bf16),
-                               int(time_major), _p(mean), _p(invstd), _p(ws), nbytes, _stream()),
+                               int(time_major), _p(mean), _p(invstd), _p(chan_sums), _p(ws), nbytes,
+                               _stream()),
           'asr_bn_act_fwd_f32')
     return out, mean, invstd
 
@@ -530,9 +531,10 @@ def _nhwc_bf16(t, what):
     return (t,) + tuple(t.shape)
 
 
-def conv7x7c32_fwd(x, weight, stride_h):
+def conv7x7c32_fwd(x, weight, stride_h, want_sums=False):
     """asr_conv7x7c32_fwd_bf16: x logical [B, 32, H, W] (channels-last bf16), weight
-    [32, 32, 7, 7] f32 -> y logical [B, 32, Ho, Wo] channels-last bf16."""
+    [32, 32, 7, 7] f32 -> y logical [B, 32, Ho, Wo] channels-last bf16 (and, want_sums, the
+    [2, 32] f64 channel sums / sums of squares of y for the following BatchNorm)."""
     x, B, C, H, W = _nhwc_bf16(x, 'x')
     weight = _dev(weight, torch.float32, 'weight')
     Ho, Wo = (H - 7) // stride_h + 1, W - 6
@@ -541,9 +543,10 @@ def conv7x7c32_fwd(x, weight, stride_h):
     L = lib()
     nbytes = L.asr_conv7x7c32_workspace_bytes()
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    check(L.asr_conv7x7c32_fwd_bf16(_p(x), _p(weight), B, H, W, int(stride_h), _p(y), _p(ws),
-                                    nbytes, _stream()), 'asr_conv7x7c32_fwd_bf16')
-    return y
+    sums = torch.empty((2, 32), dtype=torch.float64, device=x.device) if want_sums else None
+    check(L.asr_conv7x7c32_fwd_bf16(_p(x), _p(weight), B, H, W, int(stride_h), _p(y), _p(sums),
+                                    _p(ws), nbytes, _stream()), 'asr_conv7x7c32_fwd_bf16')
+    return (y, sums) if want_sums else y
 
 
 def conv7x7c32_bwd_data(dy, weight, H, W, stride_h):
@@ -576,7 +579,7 @@ def conv7x7c32_wgrad(x, dy, stride_h):
     return dw
 
 
-def conv1_fwd(x, weight):
+def conv1_fwd(x, weight, want_sums=False):
     """asr_conv1_7x7s2_fwd: x [B, T, F] f32, weight [32, 1, 7, 7] f32 -> y logical
     [B, 32, T + 6, (F - 7) // 2 + 1] channels-last bf16."""
     x = _dev(x, torch.float32, 'x')
@@ -587,9 +590,10 @@ def conv1_fwd(x, weight):
     L = lib()
     nbytes = L.asr_conv1_7x7s2_workspace_bytes()
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    check(L.asr_conv1_7x7s2_fwd(_p(x), _p(weight), B, T, F, _p(y), _p(ws), nbytes, _stream()),
-          'asr_conv1_7x7s2_fwd')
-    return y
+    sums = torch.empty((2, 32), dtype=torch.float64, device=x.device) if want_sums else None
+    check(L.asr_conv1_7x7s2_fwd(_p(x), _p(weight), B, T, F, _p(y), _p(sums), _p(ws), nbytes,
+                                _stream()), 'asr_conv1_7x7s2_fwd')
+    return (y, sums) if want_sums else y
 
 
 def conv1_wgrad(x, dy):

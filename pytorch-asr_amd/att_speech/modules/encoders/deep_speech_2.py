@@ -129,20 +129,23 @@ class DeepSpeech2(BaseEncoder):
             from att_speech.modules.encoders.native_bn import bn_hardtanh
             from att_speech.modules.encoders import native_conv
             c1 = conv[0]
+            sums1 = sums2 = None                             # channel statistics from the conv epilogues
             if bf16 and self.native_conv and native_conv.first_supported(c1, features):
-                x = native_conv.conv1(features, c1)          # hand-written MFMA kernels
+                x, sums1 = native_conv.conv1(features, c1)   # hand-written MFMA kernels
             else:
                 x = run_conv(c1, features, with_bias=False, keep_bf16=True)
-            x = bn_hardtanh(x, conv[1].batch_norm, conv[2], out_bf16=bf16, conv_bias=c1.bias)
+            x = bn_hardtanh(x, conv[1].batch_norm, conv[2], out_bf16=bf16, conv_bias=c1.bias,
+                            chan_sums=sums1)
             if bf16 and self.native_conv and native_conv.supported(c2, x):
-                y2 = native_conv.conv7x7c32(x, c2)          # hand-written MFMA kernels
+                y2, sums2 = native_conv.conv7x7c32(x, c2)
             else:
                 if bf16 and self.native_conv and not getattr(self, '_warned_conv', False):
                     self._warned_conv = True
                     warnings.warn('DeepSpeech2: the second convolution is not the 32->32 7x7 '
                                   'stride-(3,1) shape csrc/conv.hip is built for; using torch / MIOpen')
                 y2 = run_conv(c2, x, with_bias=False, keep_bf16=True)
-            x = bn_hardtanh(y2, conv[4].batch_norm, conv[5], time_major=True, conv_bias=c2.bias)
+            x = bn_hardtanh(y2, conv[4].batch_norm, conv[5], time_major=True, conv_bias=c2.bias,
+                            chan_sums=sums2)
             return x.view(x.size(0), x.size(1), -1)                  # [T', B, C*F']
         if bf16:
             x = conv[5](conv[4](second_conv(conv[2](conv[1](conv[0](features))))))

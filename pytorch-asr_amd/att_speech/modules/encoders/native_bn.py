@@ -11,11 +11,11 @@ from att_speech import _native
 class BNHardtanhFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, conv_bias, running_mean, running_var, training, momentum,
-                eps, lo, hi, out_bf16, time_major):
+                eps, lo, hi, out_bf16, time_major, chan_sums=None):
         out, mean, invstd = _native.bn_act_fwd(
             x, gamma.detach(), beta.detach(), running_mean, running_var, training, momentum,
             eps, lo, hi, out_bf16=out_bf16, time_major=time_major,
-            conv_bias=None if conv_bias is None else conv_bias.detach())
+            conv_bias=None if conv_bias is None else conv_bias.detach(), chan_sums=chan_sums)
         ctx.has_cb = conv_bias is not None
         ctx.save_for_backward(x, gamma, beta, mean, invstd,
                               conv_bias if conv_bias is not None else gamma)
@@ -29,13 +29,14 @@ class BNHardtanhFunction(torch.autograd.Function):
         dx, dgamma, dbeta, dcb = _native.bn_act_bwd(
             x, gamma.detach(), beta.detach(), mean, invstd, training, lo, hi, dy,
             time_major=time_major, conv_bias=cb.detach() if ctx.has_cb else None)
-        return (dx, dgamma, dbeta, dcb) + (None,) * 9
+        return (dx, dgamma, dbeta, dcb) + (None,) * 10
 
 
-def bn_hardtanh(x, bn, act, out_bf16=False, time_major=False, conv_bias=None):
+def bn_hardtanh(x, bn, act, out_bf16=False, time_major=False, conv_bias=None, chan_sums=None):
     """x [B,C,H,W] f32 GPU tensor -> Hardtanh(BatchNorm2d(x + conv_bias)) as f32 / bf16,
     [B,C,H,W] or time-major [H,B,C,W]; conv_bias [C] is the bias of the convolution
-    that produced x when it was run without it."""
+    that produced x when it was run without it; chan_sums [2, C] f64: that convolution's
+    per-channel (sum, sum of squares) of x, which saves the statistics pass in training."""
     use_batch_stats = bn.training or bn.running_mean is None
     momentum = 0.0
     rm = rv = None
@@ -49,4 +50,4 @@ def bn_hardtanh(x, bn, act, out_bf16=False, time_major=False, conv_bias=None):
         x = x.float()
     return BNHardtanhFunction.apply(x, bn.weight, bn.bias, conv_bias, rm, rv, use_batch_stats,
                                     momentum, bn.eps, float(act.min_val), float(act.max_val),
-                                    out_bf16, time_major)
+                                    out_bf16, time_major, chan_sums if use_batch_stats else None)

@@ -23,10 +23,12 @@ class Conv7x7C32Function(torch.autograd.Function):
     def forward(ctx, x, weight):
         x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         ctx.save_for_backward(x, weight)
-        return _native.conv7x7c32_fwd(x, weight.detach(), 3)
+        y, sums = _native.conv7x7c32_fwd(x, weight.detach(), 3, want_sums=True)
+        ctx.mark_non_differentiable(sums)
+        return y, sums
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dsums):
         x, weight = ctx.saved_tensors
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -53,19 +55,23 @@ class Conv1Function(torch.autograd.Function):
     def forward(ctx, x, weight):
         x = x.float().contiguous()
         ctx.save_for_backward(x, weight)
-        return _native.conv1_fwd(x, weight.detach())
+        y, sums = _native.conv1_fwd(x, weight.detach(), want_sums=True)
+        ctx.mark_non_differentiable(sums)
+        return y, sums
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dsums):
         x, weight = ctx.saved_tensors
         return None, (_native.conv1_wgrad(x, dy) if ctx.needs_input_grad[1] else None)
 
 
 def conv1(features, conv):
-    """features logical [B, 1, T, F] (any strides) -> conv(features) without the bias"""
+    """features logical [B, 1, T, F] (any strides) -> (conv(features) without the bias, its
+    channel sums [2, 32] f64 for the following BatchNorm)"""
     return Conv1Function.apply(features[:, 0], conv.weight)
 
 
 def conv7x7c32(x, conv):
-    """y = conv(x) without the bias: logical [B, 32, Ho, Wo] bf16, channels-last memory"""
+    """(y = conv(x) without the bias: logical [B, 32, Ho, Wo] bf16, channels-last memory;
+    channel sums [2, 32] f64 of y for the following BatchNorm)"""
     return Conv7x7C32Function.apply(x, conv.weight)

@@ -68,6 +68,26 @@ __global__ void bn_finalize_kernel(const double *sums, int C, double n, float ep
     }
 }
 
+// statistics handed over by the producer of x (the convolution's epilogue): sums [2][C] =
+// (sum x, sum x^2) of the bias-free input; the folded bias only shifts the mean
+__global__ void bn_finalize_from_sums_kernel(const double *sums, const float *shift, int C, double n,
+                                             float eps, float momentum, float *mean, float *invstd,
+                                             float *running_mean, float *running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mx = sums[c] / n;
+    double var = sums[C + c] / n - mx * mx;
+    var = var < 0.0 ? 0.0 : var;
+    const double m = mx + (shift ? (double)shift[c] : 0.0);
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
 __global__ void bn_eval_stats_kernel(const float *running_mean, const float *running_var, int C,
                                      float eps, float *mean, float *invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -385,6 +405,7 @@ extern "C" int asr_bn_act_fwd_f32(const void *x, int x_bf16, const float *conv_b
                                   int training, float momentum, float eps, float lo, float hi,
                                   void *out, int out_bf16, int out_time_major,
                                   float *save_mean, float *save_invstd,
+                                  const double *chan_sums,
                                   void *workspace, int64_t workspace_bytes, void *stream) {
     if (bad_shape(B, C, H, W) || !x || !gamma || !beta || !out || !save_mean || !save_invstd)
         return ASR_EINVAL;
@@ -398,7 +419,11 @@ extern "C" int asr_bn_act_fwd_f32(const void *x, int x_bf16, const float *conv_b
     if (x_bf16 && !channels_last) return ASR_EUNSUPPORTED;   // bf16 input: channels-last only
     const int64_t P = (int64_t)B * HW;
     const int nwg = (int)(P / 64 < 4096 ? (P / 64 > 0 ? P / 64 : 1) : 4096);
-    if (training) {
+    if (training && chan_sums) {
+        hipLaunchKernelGGL(bn_finalize_from_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, s, chan_sums,
+                           conv_bias, C, (double)B * HW, eps, momentum, save_mean, save_invstd,
+                           running_mean, running_var);
+    } else if (training) {
         hipLaunchKernelGGL(zero_doubles_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, 2 * C);
         if (channels_last)
             if (x_bf16) hipLaunchKernelGGL(bn_stats_nhwc_kernel<__bf16>, dim3(nwg), dim3(256), 0, s, (const __bf16 *)x, conv_bias, P, C, sums);

@@ -26,6 +26,45 @@ constexpr int KS = 7;             // kernel size (both axes)
 constexpr int PIX = 80;           // bytes per pixel in LDS
 constexpr int KSTEPS = KS * KS * CH / 16;      // 98 MFMA k-steps of 16
 
+// ---- per-channel statistics of an output image in LDS -------------------------------------
+// oimg [npix][32] bf16 -> partial[64] = (sum over pixels, sum of squares) per channel, by
+// 256 threads (8 pixel groups x 32 channels); `red` = 512 floats of LDS scratch
+__device__ __forceinline__ void chan_partial_sums(const __bf16 *oimg, int npix, float *red, float *partial) {
+    const int tid = threadIdx.x, ch = tid & 31, grp = tid >> 5;
+    float s = 0.f, q = 0.f;
+    for (int m = grp; m < npix; m += 8) {
+        const float v = (float)oimg[m * CH + ch];
+        s += v;
+        q += v * v;
+    }
+    red[grp * 64 + ch] = s;
+    red[grp * 64 + 32 + ch] = q;
+    __syncthreads();
+    if (tid < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g * 64 + tid];
+        partial[tid] = t;
+    }
+}
+
+// chan_sums[e] = sum over the workgroups' partial[g][e], e < 64, in double
+__global__ __launch_bounds__(1024) void chan_sums_reduce_kernel(const float *partial, int nparts, double *out) {
+    __shared__ double lds[1024];
+    const int el = threadIdx.x & 63, way = threadIdx.x >> 6;
+    double s = 0.0;
+    for (int g = blockIdx.x * 16 + way; g < nparts; g += gridDim.x * 16) s += (double)partial[(size_t)g * 64 + el];
+    lds[way * 64 + el] = s;
+    __syncthreads();
+    if (way == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += lds[w * 64 + el];
+        atomicAdd(out + el, t);
+    }
+}
+
+__global__ void zero_chan_sums_kernel(double *out) { out[threadIdx.x] = 0.0; }
+
 // ---- weight packing -------------------------------------------------------------------
 // forward: B[k][n], k = (kt * 7 + kf) * 32 + ci, n = co.
 // fragment of k-step s for lane l: B[16 s + 8 (l >> 5) + j][l & 31], j = 0..7
@@ -42,6 +81,7 @@ struct ConvFwdParams {
     const __bf16 *x;
     const __bf16 *wpack;
     __bf16 *y;
+    float *stats;                 // [workgroups][64] channel sums of the outputs, or null
     int B, H, W, Ho, Wo, R;       // R output rows per workgroup (R * Wo <= 192)
 };
 
@@ -134,14 +174,16 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
             }
     }
     __syncthreads();
+    const int rows_here = (p.Ho - ho0) < R ? (p.Ho - ho0) : R;
     {
-        const int rows_here = (p.Ho - ho0) < R ? (p.Ho - ho0) : R;
         const int chunks = rows_here * Wo * 4;
         char *yb = reinterpret_cast<char *>(p.y) + ((size_t)b * p.Ho + ho0) * Wo * 64;
         for (int c = tid; c < chunks; c += 256)
             *reinterpret_cast<u32x4 *>(yb + (size_t)c * 16) =
                 *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(oimg) + (size_t)c * 16);
     }
+    if (p.stats)        // `part` (the k-half exchange) is free again: scratch
+        chan_partial_sums(oimg, rows_here * Wo, part, p.stats + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64);
 }
 
 
@@ -517,6 +559,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Params p) {
     for (int c = tid; c < rows_here * Fo * 4; c += 256)
         *reinterpret_cast<u32x4 *>(yb + (size_t)c * 16) =
             *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(oimg) + (size_t)c * 16);
+    if (p.partial)      // channel sums of the outputs; scratch behind the output image
+        chan_partial_sums(oimg, rows_here * Fo, reinterpret_cast<float *>(oimg + (size_t)ntiles * 32 * CH),
+                          p.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64);
 }
 
 // weight gradient: dw[co][kt][kf] = sum_{b,t,fo} dy[b,t,fo,co] * x[b, t + kt - 6, 2 fo + kf]
@@ -607,7 +652,7 @@ extern "C" int64_t asr_conv7x7c32_workspace_bytes(void) {
 }
 
 extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int H, int W,
-                                       int stride_h, void *y, void *workspace,
+                                       int stride_h, void *y, double *chan_sums, void *workspace,
                                        int64_t workspace_bytes, void *stream) {
     if (B <= 0 || H < KS || W < KS) return ASR_EINVAL;
     if (!x || !w || !y || !workspace || workspace_bytes < asr_conv7x7c32_workspace_bytes())
@@ -628,11 +673,18 @@ extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int
     p.x = (const __bf16 *)x; p.wpack = wpack; p.y = (__bf16 *)y;
     p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.R = R;
     const dim3 grid((Ho + R - 1) / R, B);
+    // the weight gradient's partial-sum area doubles as the statistics' (never live together)
+    p.stats = chan_sums ? (float *)((char *)workspace + (size_t)KSTEPS * 64 * 8 * 2 * 2) : nullptr;
+    if (chan_sums && (int64_t)grid.x * grid.y * 64 * 4 > (int64_t)WGRAD_WGS * 49 * 1024 * 4) return ASR_EUNSUPPORTED;
     void (*kern)(ConvFwdParams) = stride_h == 3 ? conv7x7c32_fwd_kernel<3> : conv7x7c32_fwd_kernel<1>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ASR_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    if (chan_sums) {
+        hipLaunchKernelGGL(zero_chan_sums_kernel, dim3(1), dim3(64), 0, s, chan_sums);
+        hipLaunchKernelGGL(chan_sums_reduce_kernel, dim3(64), dim3(1024), 0, s, p.stats, (int)(grid.x * grid.y), chan_sums);
+    }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
@@ -704,7 +756,9 @@ extern "C" int asr_conv7x7c32_wgrad_bf16(const void *x, const void *dy, int B, i
 }
 
 extern "C" int64_t asr_conv1_7x7s2_workspace_bytes(void) {
-    return 4 * 64 * 8 * 2 + (int64_t)C1_WGS * 2 * 1024 * 4 + 256;
+    // packed weights + max(weight-gradient partials, 64 channel sums per forward workgroup: up
+    // to 2^17 workgroups)
+    return 4 * 64 * 8 * 2 + (int64_t)(1 << 17) * 64 * 4 + 256;
 }
 
 static int conv1_shapes(int B, int T, int F, int *To, int *Fo) {
@@ -716,7 +770,8 @@ static int conv1_shapes(int B, int T, int F, int *To, int *Fo) {
 }
 
 extern "C" int asr_conv1_7x7s2_fwd(const float *x, const float *w, int B, int T, int F, void *y,
-                                   void *workspace, int64_t workspace_bytes, void *stream) {
+                                   double *chan_sums, void *workspace, int64_t workspace_bytes,
+                                   void *stream) {
     int To, Fo;
     const int rc = conv1_shapes(B, T, F, &To, &Fo);
     if (rc != ASR_OK) return rc;
@@ -726,12 +781,21 @@ extern "C" int asr_conv1_7x7s2_fwd(const float *x, const float *w, int B, int T,
     __bf16 *wpack = (__bf16 *)workspace;
     hipLaunchKernelGGL(conv1_pack_kernel, dim3(8), dim3(256), 0, s, w, wpack);
     Conv1Params p;
-    p.x = x; p.wpack = wpack; p.y = (__bf16 *)y; p.partial = nullptr;
+    p.x = x; p.wpack = wpack; p.y = (__bf16 *)y;
     p.B = B; p.T = T; p.F = F; p.To = To; p.Fo = Fo;
+    const dim3 grid((To + C1_ROWS - 1) / C1_ROWS, B);
+    // the weight gradient's partial-sum area doubles as the statistics' (never live together)
+    p.partial = chan_sums ? (float *)((char *)workspace + 4 * 64 * 8 * 2) : nullptr;
+    if (chan_sums && (int64_t)grid.x * grid.y * 64 * 4 > asr_conv1_7x7s2_workspace_bytes() - 4 * 64 * 8 * 2 - 256)
+        return ASR_EUNSUPPORTED;
     const int ntiles = (C1_ROWS * Fo + 31) / 32;
-    const size_t lds = (size_t)(C1_ROWS + 8) * Fo * 16 + (size_t)ntiles * 32 * CH * 2;
+    const size_t lds = (size_t)(C1_ROWS + 8) * Fo * 16 + (size_t)ntiles * 32 * CH * 2 + 512 * 4;
     if (lds > 64 * 1024) return ASR_EUNSUPPORTED;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((To + C1_ROWS - 1) / C1_ROWS, B), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(conv1_fwd_kernel, grid, dim3(256), lds, s, p);
+    if (chan_sums) {
+        hipLaunchKernelGGL(zero_chan_sums_kernel, dim3(1), dim3(64), 0, s, chan_sums);
+        hipLaunchKernelGGL(chan_sums_reduce_kernel, dim3(64), dim3(1024), 0, s, p.partial, (int)(grid.x * grid.y), chan_sums);
+    }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 

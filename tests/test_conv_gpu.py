@@ -23,8 +23,12 @@ def test_conv_forward_matches_conv2d(B, H, W, sh):
     x, w = _inputs(B, H, W, B * 100 + H)
     dev = torch.device('cuda:0')
     xb = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    y = _native.conv7x7c32_fwd(xb, w.to(dev), sh)
+    y, sums = _native.conv7x7c32_fwd(xb, w.to(dev), sh, want_sums=True)
     torch.cuda.synchronize()
+    # the epilogue's channel statistics are those of the bf16 outputs themselves
+    yd = y.double()
+    np.testing.assert_allclose(sums[0].cpu().numpy(), yd.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(sums[1].cpu().numpy(), (yd * yd).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5)
     # reference on the SAME bf16-rounded operands, fp32 arithmetic
     want = F.conv2d(xb.float().cpu(), w.to(torch.bfloat16).float(), None, (sh, 1))
     assert tuple(y.shape) == tuple(want.shape)
@@ -82,7 +86,10 @@ def test_first_convolution_forward_and_weight_gradient(B, T, F):
     x = torch.randn(B, T, F, generator=g)
     w = torch.randn(32, 1, 7, 7, generator=g) * 0.1
     dev = torch.device('cuda:0')
-    y = _native.conv1_fwd(x.to(dev), w.to(dev))
+    y, sums = _native.conv1_fwd(x.to(dev), w.to(dev), want_sums=True)
+    yd = y.double()
+    np.testing.assert_allclose(sums[0].cpu().numpy(), yd.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(sums[1].cpu().numpy(), (yd * yd).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5)
     xr = x.to(torch.bfloat16).float()[:, None]                       # operands as the kernel rounds them
     want = F_conv(xr, w.to(torch.bfloat16).float())
     got = y.float().cpu()
