@@ -205,7 +205,8 @@ int asr_lattice_grouped_forward_f32(
  * and carry no gradient, which reproduces pack_padded_sequence semantics
  * (the reverse direction starts at each utterance's own last frame).
  *   y      [T,B,2,H]   per-direction hidden outputs (the reference sums the
- *                      two directions, encoder_utils.py:112-117)
+ *                      two directions, encoder_utils.py:112-117); may be null when the
+ *                      caller only needs the bf16 copy below (inner layers of a stack)
  *   y_bf16 [2,T+2,B,H] bf16 copy, direction-major, frame t at index t+1 with a
  *                      zero frame at both ends: h_{t-1} of the forward
  *                      direction is the slice [0][0:T], of the reverse

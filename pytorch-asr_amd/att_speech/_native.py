@@ -275,7 +275,7 @@ def lstm_check_errors():
                 'NaN. Set ASR_LSTM_PERSIST=0 to use one launch per time step.' % idx)
 
 
-def lstm_bidir_fwd(gx, whh_bf16, lens):
+def lstm_bidir_fwd(gx, whh_bf16, lens, want_y=True):
     """asr_lstm_bidir_fwd_bf16: gx [T,B,2,4H] f32 or bf16, whh [2,4H,H] bf16, lens [B] i32
     -> (y [T,B,2,H] f32, y_bf16 [2,T+2,B,H], gates [T,2,B,H,4] bf16, csave [T,2,B,H])."""
     gx = _dev(gx, gx.dtype if gx.dtype == torch.bfloat16 else torch.float32, 'gx')
@@ -284,7 +284,7 @@ def lstm_bidir_fwd(gx, whh_bf16, lens):
     T, B, _, H4 = gx.shape
     H = H4 // 4
     L = lib()
-    y = torch.empty((T, B, 2, H), dtype=torch.float32, device=gx.device)
+    y = torch.empty((T, B, 2, H), dtype=torch.float32, device=gx.device) if want_y else None
     ybf = torch.empty((2, T + 2, B, H), dtype=torch.bfloat16, device=gx.device)
     gates = torch.empty((T, 2, B, H, 4), dtype=torch.bfloat16, device=gx.device)
     csave = torch.empty((T, 2, B, H), dtype=torch.float32, device=gx.device)

@@ -9,6 +9,7 @@ one) and lets the input projection run as one dense [T*B, F] GEMM."""
 from __future__ import division, print_function
 
 import inspect
+import os
 import warnings
 
 import torch
@@ -135,7 +136,20 @@ class SequentialWithOptionalAttributes(nn.Sequential):
     """reference :127-133 (py3: inspect instead of func_code); modules that
     take (x, lens, ...) return (x, lens)."""
 
+    def _plain_native_stack(self, x):
+        """every module a BatchRNN that is nothing but a native bidirectional LSTM with summed
+        directions: the whole stack runs as one autograd node (native_lstm.bilstm_stack)"""
+        mods = list(self._modules.values())
+        return len(mods) > 1 and all(
+            isinstance(m, BatchRNN) and m._use_native(x) and m.projection is None
+            and not m.subsample and not m.residual
+            and isinstance(m.batch_norm.batch_norm, Identity) for m in mods)
+
     def forward(self, input, lens, *args):
+        if os.environ.get('ASR_LSTM_STACK', '1') != '0' and self._plain_native_stack(input):
+            from att_speech.modules.encoders.native_lstm import bilstm_stack
+            lens_t = torch.as_tensor(lens)
+            return bilstm_stack(input, lens_t, [m.rnn for m in self._modules.values()]), lens_t
         for module in self._modules.values():
             if isinstance(module, BatchRNN):
                 nparams = len(inspect.signature(module.forward).parameters)

@@ -90,6 +90,77 @@ class BiLSTMFunction(torch.autograd.Function):
         return dx, None, dw_ih[:4 * H], dw_hh[0], dw_ih[4 * H:], dw_hh[1], None
 
 
+def _weight_gradients(dgb, xb, ybf, T, B, H, F):
+    """dW_ih [2*4H, F] and dW_hh[d] [4H, H] from the gate gradients (see BiLSTMFunction.backward)"""
+    TB = T * B
+    dg2 = dgb.view(TB, 8 * H)
+    g1, g2 = _chunks(TB, 16), _chunks(TB, 32)
+    dw_ih = _native.sum_leading(_bmm_f32(dg2.view(g1, TB // g1, 8 * H).transpose(1, 2),
+                                         xb.view(g1, TB // g1, F)))
+    dgd = dgb.view(g2, TB // g2, 2, 4 * H)
+    dw_hh = [_native.sum_leading(_bmm_f32(
+        dgd[:, :, d].transpose(1, 2),
+        (ybf[0, 0:T] if d == 0 else ybf[1, 2:T + 2]).reshape(g2, TB // g2, H)))
+        for d in range(2)]
+    return dw_ih, dw_hh
+
+
+class BiLSTMStackFunction(torch.autograd.Function):
+    """A stack of bidirectional LSTM layers whose directions are summed between layers
+    (BatchRNN x N without normalisation / projection / residual, encoder_utils.py:97-124) as
+    ONE autograd node: between layers only the bf16 hidden planes the recurrence writes
+    anyway are read — layer l+1's GEMM operand is bf16(h_fwd) + bf16(h_rev) — so the inner
+    layers write no fp32 outputs, and no fp32 direction sum or cast pass runs between them
+    (0.17 ms per layer at B=576); the gradient travels between layers in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, lens_dev, *weights):
+        T, B, F = x.shape
+        n = len(weights) // 4
+        saved, xb = [], x.reshape(T * B, F).to(torch.bfloat16)
+        for l in range(n):
+            w_ih_f, w_hh_f, w_ih_r, w_hh_r = weights[4 * l:4 * l + 4]
+            H = w_hh_f.shape[1]
+            w_ih = torch.cat([w_ih_f, w_ih_r], 0).to(torch.bfloat16)
+            gx = torch.mm(xb, w_ih.t()).view(T, B, 2, 4 * H)
+            whh = torch.stack([w_hh_f, w_hh_r], 0).to(torch.bfloat16).contiguous()
+            last = l == n - 1
+            y, ybf, gates, csave = _native.lstm_bidir_fwd(gx, whh, lens_dev, want_y=last)
+            saved += [xb, w_ih, whh, ybf, gates, csave]
+            if not last:
+                xb = (ybf[0, 1:T + 1] + ybf[1, 1:T + 1]).view(T * B, H)
+        ctx.save_for_backward(lens_dev, *saved)
+        ctx.n = n
+        return y.sum(2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lens_dev, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        grads = [None] * (4 * ctx.n)
+        dy = dy.contiguous()
+        for l in range(ctx.n - 1, -1, -1):
+            xb, w_ih, whh, ybf, gates, csave = saved[6 * l:6 * l + 6]
+            _, T2, B, H = ybf.shape
+            T, F = T2 - 2, xb.shape[1]
+            dgb = _native.lstm_bidir_bwd(dy, whh.transpose(1, 2).contiguous(), lens_dev, gates, csave)
+            dw_ih, dw_hh = _weight_gradients(dgb, xb, ybf, T, B, H, F)
+            grads[4 * l:4 * l + 4] = [dw_ih[:4 * H], dw_hh[0], dw_ih[4 * H:], dw_hh[1]]
+            if l > 0 or ctx.needs_input_grad[0]:
+                dy = _mm_f32(dgb.view(T * B, 8 * H), w_ih.t().contiguous().t()).view(T, B, F)
+        return (dy if ctx.needs_input_grad[0] else None, None) + tuple(grads)
+
+
+def bilstm_stack(x, lens, rnns):
+    """x [T,B,F] GPU tensor through the nn.LSTM modules `rnns` (bidirectional, bias-free,
+    one layer each), directions summed after every layer -> [T,B,H] f32."""
+    lens_dev = torch.as_tensor(lens).to(x.device, torch.int32)
+    weights = []
+    for rnn in rnns:
+        weights += [rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.weight_ih_l0_reverse,
+                    rnn.weight_hh_l0_reverse]
+    return BiLSTMStackFunction.apply(x.contiguous(), lens_dev, *weights)
+
+
 def bilstm(x, lens, rnn, sum_dirs=False):
     """x [T,B,F] GPU tensor, lens [B] (any int tensor), rnn: nn.LSTM(bidirectional,
     bias=False, 1 layer).  Returns per-direction outputs [T,B,2,H], or their sum

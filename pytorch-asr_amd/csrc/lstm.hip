@@ -273,13 +273,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
                 lstm_cell_fwd(pre, pc[e], gt, c, h);
                 p.cbuf[sidx] = c;
                 hnext[frag_off(b, j, KS)] = (__bf16)h;
-                *yo = h;
+                if (p.y) *yo = h;
                 *ybo = (__bf16)h;
                 p.gates[csv] = pack_gates(gt);
                 p.csave[csv] = c;
             } else {
                 hnext[frag_off(b, j, KS)] = hprev[frag_off(b, j, KS)];
-                *yo = 0.f;
+                if (p.y) *yo = 0.f;
                 *ybo = (__bf16)0.f;
                 p.csave[csv] = pc[e];
             }
@@ -544,7 +544,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     const u32 fcs = (u32)B * 2u * H * 4u, fg = (u32)B * 2u * H * 8u;
     const __amdgpu_buffer_rsrc_t gxR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(p.gx), 0, (int)((u32)T * fgx), 0x00020000);
-    const __amdgpu_buffer_rsrc_t yR = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((u32)T * fy), 0x00020000);
+    // y == null: zero records, every fp32 output store is dropped by the bounds check
+    const __amdgpu_buffer_rsrc_t yR = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y ? (int)((u32)T * fy) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ybR = __builtin_amdgcn_make_buffer_rsrc(
         p.ybf, 0, (int)((u32)(2 * (T + 2)) * fyb), 0x00020000);
     const __amdgpu_buffer_rsrc_t csR = __builtin_amdgcn_make_buffer_rsrc(p.csave, 0, (int)((u32)T * fcs), 0x00020000);
@@ -1049,7 +1050,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
                                        uint32_t *err_flag, void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0) return ASR_EINVAL;
     if (T == 0) return ASR_OK;
-    if (!gx || !whh_bf16 || !lens || !y || !y_bf16 || !gates_bf16 || !csave || !workspace)
+    if (!gx || !whh_bf16 || !lens || !y_bf16 || !gates_bf16 || !csave || !workspace)
         return ASR_EINVAL;
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;

@@ -147,3 +147,34 @@ def test_handoff_timeout_surfaces_as_an_error(monkeypatch):
     y = bilstm(x, lens, rnn)
     _native.lstm_check_errors()                       # the word was cleared by the raise
     assert bool(torch.isfinite(y).all())
+
+
+def test_layer_stack_matches_chained_layers():
+    """native_lstm.bilstm_stack (one autograd node, bf16 planes between layers, no fp32 outputs
+    of the inner layers) against the same layers applied one by one with summed directions:
+    outputs and all gradients agree at the level of the bf16 inter-layer operand."""
+    from att_speech.modules.encoders.native_lstm import bilstm, bilstm_stack
+    torch.manual_seed(5)
+    dev = torch.device('cuda:0')
+    T, B, F, H = 23, 37, 96, 128
+    lens = torch.tensor(sorted(np.random.RandomState(3).randint(1, T + 1, size=B).tolist(), reverse=True))
+    lens[0] = T
+    rnns = [nn.LSTM(F if l == 0 else H, H, bidirectional=True, bias=False).to(dev) for l in range(3)]
+    x = torch.randn(T, B, F, device=dev)
+    dy = torch.randn(T, B, H, device=dev) * (torch.arange(T, device=dev)[:, None, None] < lens.to(dev)[None, :, None])
+
+    xa = x.clone().requires_grad_()
+    y = xa
+    for r in rnns:
+        y = bilstm(y, lens, r, sum_dirs=True)
+    y.backward(dy)
+    want = [y.detach(), xa.grad] + [p.grad.clone() for r in rnns for p in r.parameters()]
+    for r in rnns:
+        r.zero_grad()
+    xb = x.clone().requires_grad_()
+    y2 = bilstm_stack(xb, lens, rnns)
+    y2.backward(dy)
+    got = [y2.detach(), xb.grad] + [p.grad for r in rnns for p in r.parameters()]
+    for a, b_ in zip(got, want):
+        scale = float(b_.abs().max())
+        assert float((a - b_).abs().max()) <= 2e-2 * scale + 1e-6
