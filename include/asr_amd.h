@@ -291,6 +291,20 @@ int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_bias, int B,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
+ * log_softmax over all C classes followed by the per-frame max stabilisation of
+ * FSTDecoder.get_fst_loss (advanced_decoder.py:444-452 with normalize_by_dim = 0, then
+ * :479-484) in ONE pass over x [T, B, C]: y = log_softmax(x) - max_c log_softmax(x) = x - max_c x,
+ * nls [T, B] = max_c log_softmax(x) (= -log sum_c exp(x - max x)), nls_sum [B] = sum over the
+ * frames t < lens[b] of nls — the value the reference subtracts as its denominator when
+ * denominator_red = 'none'.  bwd: dx = dy - exp(y + nls) * sum_c dy, the gradient of the
+ * log-softmax (the reference detaches the maximum), from the shifted y itself.
+ */
+int asr_log_softmax_shift_fwd_f32(const float *x, int T, int B, int C, const int32_t *lens,
+                                  float *y, float *nls, float *nls_sum, void *stream);
+int asr_log_softmax_shift_bwd_f32(const float *y, const float *nls, const float *dy, int64_t rows,
+                                  int C, float *dx, void *stream);
+
+/*
  * out[e] = sum over g < G of in[g * n + e] (n % 4 == 0): the sum of the partial products of a
  * weight-gradient GEMM split over chunks of frames (torch's strided reduction reads at
  * 1.4 TB/s here).

@@ -47,6 +47,8 @@ _SIGNATURES = {
     'asr_conv1_7x7s2_workspace_bytes': (_i64, []),
     'asr_conv1_7x7s2_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_conv1_7x7s2_wgrad': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    'asr_log_softmax_shift_fwd_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'asr_log_softmax_shift_bwd_f32': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     'asr_sum_leading_f32': (_i, [_vp, _i, _i64, _vp, _vp]),
     'asr_tcn_attention_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                         _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -620,3 +622,25 @@ def sum_leading(t):
     check(lib().asr_sum_leading_f32(_p(t), t.shape[0], t[0].numel(), _p(out), _stream()),
           'asr_sum_leading_f32')
     return out
+
+
+def log_softmax_shift_fwd(x, lens):
+    """asr_log_softmax_shift_fwd_f32: x [T, B, C] -> (y = x - max_c x, nls [T, B], nls_sum [B])"""
+    x = _dev(x, torch.float32, 'logits')
+    lens = _dev(lens, torch.int32, 'lens')
+    T, B, C = x.shape
+    y = torch.empty_like(x)
+    nls = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    nls_sum = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(lib().asr_log_softmax_shift_fwd_f32(_p(x), T, B, C, _p(lens), _p(y), _p(nls), _p(nls_sum),
+                                              _stream()), 'asr_log_softmax_shift_fwd_f32')
+    return y, nls, nls_sum
+
+
+def log_softmax_shift_bwd(y, nls, dy):
+    y, dy = _dev(y, torch.float32, 'y'), _dev(dy, torch.float32, 'dy')
+    C = y.shape[-1]
+    dx = torch.empty_like(y)
+    check(lib().asr_log_softmax_shift_bwd_f32(_p(y), _p(nls), _p(dy), y.numel() // C, C, _p(dx),
+                                              _stream()), 'asr_log_softmax_shift_bwd_f32')
+    return dx

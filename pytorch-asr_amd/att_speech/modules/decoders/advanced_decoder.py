@@ -389,6 +389,24 @@ class _SubRowMax(torch.autograd.Function):
         return dshifted, None
 
 
+class _NormaliseShift(torch.autograd.Function):
+    """get_normalized_acts(normalize_by_dim=0) followed by _SubRowMax in one pass over the
+    logits (asr_log_softmax_shift_*): the normaliser cancels in the shifted acts and only
+    enters the per-utterance sum of row maxima."""
+
+    @staticmethod
+    def forward(ctx, acts, lens_dev):
+        shifted, nls, nls_sum = _native.log_softmax_shift_fwd(acts.contiguous(), lens_dev)
+        ctx.save_for_backward(shifted, nls)
+        ctx.mark_non_differentiable(nls_sum)
+        return shifted, nls_sum
+
+    @staticmethod
+    def backward(ctx, dshifted, _):
+        shifted, nls = ctx.saved_tensors
+        return _native.log_softmax_shift_bwd(shifted, nls, dshifted.contiguous()), None
+
+
 class FSTDecoder(_ProjectionDecoder):
     """Lattice-based decoder: loss = numerator reduction over the utterance's
     training graph minus a denominator (reduction over the decoding graph, or the
@@ -437,11 +455,17 @@ class FSTDecoder(_ProjectionDecoder):
             self._verify = True
         return given
 
-    def get_fst_loss(self, logits, encoded_lens, texts, text_lens, other_data_in_batch):
+    def get_fst_loss(self, logits, encoded_lens, texts, text_lens, other_data_in_batch,
+                     unnormalised=False):
+        """`unnormalised`: `logits` are the raw acts of a decoder with normalize_by_dim = 0;
+        normalisation and stabilisation then run as one pass"""
         gg = self.graph_generator
         numerator = self._numerator_graphs(texts, text_lens, other_data_in_batch, logits.device)
         lens_dev = torch.as_tensor(encoded_lens).to(logits.device, torch.int32)
-        shifted, max_sum = _SubRowMax.apply(logits, lens_dev)            # (:479-484)
+        if unnormalised:
+            shifted, max_sum = _NormaliseShift.apply(logits, lens_dev)   # (:444-452) + (:479-484)
+        else:
+            shifted, max_sum = _SubRowMax.apply(logits, lens_dev)        # (:479-484)
         num = -fst_utils.path_reduction(shifted, encoded_lens, numerator,
                                         red_kind=self.numerator_red, neg_inf=gg.nc_weight)
         if self.denominator_red == 'none':
@@ -458,8 +482,13 @@ class FSTDecoder(_ProjectionDecoder):
 
     def forward(self, encoded, encoded_lens, texts, text_lens, spkids=None,
                 **other_data_in_batch):
-        total = self.get_fst_loss(self.logits(encoded, encoded_lens), encoded_lens,
-                                  texts, text_lens, other_data_in_batch).sum()
+        if self.normalize_by_dim == 0 and self.normalize_by_dim is not None and encoded.is_cuda:
+            losses = self.get_fst_loss(self.fc(encoded), encoded_lens, texts, text_lens,
+                                       other_data_in_batch, unnormalised=True)
+        else:
+            losses = self.get_fst_loss(self.logits(encoded, encoded_lens), encoded_lens,
+                                       texts, text_lens, other_data_in_batch)
+        total = losses.sum()
         return {'fst_loss': total, 'loss': total}
 
     def decode(self, encoded, encoded_lens, texts=None, text_lens=None,

@@ -252,3 +252,108 @@ extern "C" int asr_sum_leading_f32(const float *in, int G, int64_t n, float *out
                        (hipStream_t)stream, (const float4 *)in, G, n4, (float4 *)out);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
+
+
+// -----------------------------------------------------------------------------------------
+// Normalise + stabilise in one pass (FSTDecoder with normalize_by_dim = 0 and the row-max
+// stabilisation of advanced_decoder.py:479-484): log_softmax(x) - max_c log_softmax(x) is
+// x - max_c x — the normaliser cancels — so the shifted acts are written straight from the
+// logits and the normaliser only enters the per-row constant
+//     nls[r] = max_c log_softmax(x[r]) = -log sum_c exp(x[r,c] - max_c x[r]),
+// whose masked sum over frames is the 'denominator' the reference subtracts.  The backward
+// pass needs softmax(x) = exp(shifted + nls): it is recomputed, no normalised copy is kept.
+// One read + one write of [rows, C] forward instead of two of each.
+// -----------------------------------------------------------------------------------------
+namespace {
+using namespace asr;
+
+template <int PER>
+__global__ void lsm_shift_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                     float *__restrict__ nls, int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float *xr = x + r * C;
+        float v[PER];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * 64 + lane;
+            v[i] = c < C ? xr[c] : -INFINITY;
+            m = fmaxf(m, v[i]);
+        }
+        m = wave_max(m);
+        float s = 0.f;
+        float *yr = y + r * C;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * 64 + lane;
+            const float d = v[i] - m;
+            s += __expf(d);
+            if (c < C) yr[c] = d;
+        }
+        s = wave_sum(s);
+        if (lane == 0) nls[r] = -__logf(s);
+    }
+}
+
+template <int PER>
+__global__ void lsm_shift_bwd_kernel(const float *__restrict__ y, const float *__restrict__ nls,
+                                     const float *__restrict__ dy, float *__restrict__ dx,
+                                     int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float *yr = y + r * C, *gr = dy + r * C;
+        const float off = nls[r];
+        float vy[PER], vg[PER];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * 64 + lane;
+            vy[i] = c < C ? yr[c] : -INFINITY;
+            vg[i] = c < C ? gr[c] : 0.f;
+            s += vg[i];
+        }
+        s = wave_sum(s);
+        float *dr = dx + r * C;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * 64 + lane;
+            if (c < C) dr[c] = vg[i] - __expf(vy[i] + off) * s;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int asr_log_softmax_shift_fwd_f32(const float *x, int T, int B, int C,
+                                             const int32_t *lens, float *y, float *nls,
+                                             float *nls_sum, void *stream) {
+    if (T < 0 || B < 0 || C <= 0) return ASR_EINVAL;
+    if (B == 0) return ASR_OK;
+    if (!lens || !nls_sum) return ASR_EINVAL;
+    if (T > 0 && (!x || !y || !nls)) return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rows = (int64_t)T * B;
+    if (T > 0) {
+#define CALL(P) hipLaunchKernelGGL(lsm_shift_fwd_kernel<P>, dim3(grid_for(rows)), dim3(256), 0, s, x, y, nls, rows, C)
+        DISPATCH_PER(C, CALL);
+#undef CALL
+    }
+    hipLaunchKernelGGL(max_sum_kernel, dim3(B), dim3(64), 0, s, nls, lens, nls_sum, T, B);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_log_softmax_shift_bwd_f32(const float *y, const float *nls, const float *dy,
+                                             int64_t rows, int C, float *dx, void *stream) {
+    if (rows < 0 || C <= 0) return ASR_EINVAL;
+    if (rows == 0) return ASR_OK;
+    if (!y || !nls || !dy || !dx) return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(P) hipLaunchKernelGGL(lsm_shift_bwd_kernel<P>, dim3(grid_for(rows)), dim3(256), 0, s, y, nls, dy, dx, rows, C)
+    DISPATCH_PER(C, CALL);
+#undef CALL
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}

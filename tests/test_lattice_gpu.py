@@ -472,3 +472,28 @@ def test_full_size_grouped_denominator_properties():
     assert not grad[~mask].any() and grad.min() >= 0.0
     # locally normalised inputs: the sum over ALL label sequences of the decoding graph is <= 1
     assert (logZ <= 1e-3).all()
+
+
+@pytest.mark.parametrize('T,B,C', [(23, 5, 49), (9, 3, 2401), (4, 2, 7), (50, 4, 130)])
+def test_fused_normalise_and_shift(T, B, C):
+    """asr_log_softmax_shift_{fwd,bwd}_f32 == log_softmax followed by the row-max subtraction
+    (get_normalized_acts + advanced_decoder.py:479-484) and the gradient of that composition
+    with the maximum detached"""
+    from att_speech import _native
+    rng = np.random.default_rng(T * 7 + C)
+    x = torch.from_numpy(rng.standard_normal((T, B, C)).astype(np.float32) * 4)
+    lens = torch.tensor(sorted(rng.integers(0, T + 1, size=B).tolist(), reverse=True), dtype=torch.int32)
+    d = dev()
+    y, nls, nls_sum = _native.log_softmax_shift_fwd(x.to(d), lens.to(d))
+    xr = x.double().requires_grad_()
+    lp = torch.log_softmax(xr, -1)
+    mx = lp.max(-1, keepdim=True)[0].detach()
+    want = lp - mx
+    np.testing.assert_allclose(y.cpu().numpy(), want.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(nls.cpu().numpy(), mx.squeeze(-1).numpy(), rtol=1e-5, atol=1e-6)
+    mask = (torch.arange(T)[:, None] < lens[None, :]).double()
+    np.testing.assert_allclose(nls_sum.cpu().numpy(), (mx.squeeze(-1) * mask).sum(0).numpy(), rtol=1e-5, atol=1e-5)
+    dy = torch.from_numpy(rng.standard_normal((T, B, C)).astype(np.float32))
+    want.backward(dy.double())
+    dx = _native.log_softmax_shift_bwd(y, nls, dy.to(d))
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), atol=2e-5)
