@@ -231,7 +231,7 @@ def cpu_baseline(T, order, dev=None, state_dict=None, seconds_budget=15.0):
     return base, delta
 
 
-def bichar_numerator_roofline(dev, B=512, Tp=334, iters=10):
+def bichar_numerator_roofline(dev, B=512, Tp=334, iters=10, traffic=None):
     """The alpha/beta scan alone on the bi-char numerator (ctc_bi shape: C = 2401,
     L_b = 100 - 2 (b mod 16), all utterances Tp frames): average launch time from
     events on the launch stream / SURVEY.md §8d algorithmic bytes."""
@@ -261,7 +261,7 @@ def bichar_numerator_roofline(dev, B=512, Tp=334, iters=10):
     return {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan), bi-char numerator '
                                       'C=2401 B=%d T\'=%d' % (B, Tp),
             'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
-            'traffic': None, 'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': ms}
+            'traffic': traffic, 'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': ms}
 
 
 def tcn_decode_rate(dev, B=64, T=1000, beam=10, steps=120):
@@ -344,29 +344,24 @@ def dry_run(a, world, rank):
         dist.destroy_process_group()
 
 
-def pmc_traffic(order, B, T):
+def pmc_traffic(order, B, T, kernel_tag=None):
     """HBM bytes per lattice launch from the PMC passes committed under profiles/
-    (r01_pmc_step_fetch_write.json / r01_pmc_lattice_fetch_write.json: separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs of bench.py (tools/pmc_summary.py) / tools/bench_lattice.py, T'=334; FETCH_SIZE reads half of a 4 B/lane coalesced
-    stream on gfx950 - calibrated on log_softmax_fwd - so traffic = 2*FETCH + WRITE).
-    bench.py cannot collect counters itself; the figure applies to the measured shape only."""
+    (r02_pmc_step_fetch_write.json: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    runs of bench.py summarised by tools/pmc_summary.py; FETCH_SIZE counts half of a
+    4 B/lane coalesced stream on gfx950 - calibrated on log_softmax_fwd - so
+    traffic = 2*FETCH + WRITE).  bench.py cannot collect counters itself; the figure
+    applies to the measured shape only (T = 1000 frames, the batch recorded in the file;
+    the bi-char numerator launch of `roofline_bichar` is part of the same runs)."""
     if T != 1000:
         return None
-    k = 'lattice_fwbw_sl_kernel<3, 8, 1>' if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>'
-    try:    # passes over bench.py itself (the lattice launch inside the training step)
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_step_fetch_write.json')))
-        if pmc.get('batch', 512) != B:
+    k = kernel_tag or ('lattice_fwbw_sl_kernel<3, 8, 1>' if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>')
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_step_fetch_write.json')))
+        if pmc.get('batch') != B:
             return None
         e = next(v for n, v in pmc['kernels'].items() if k in n)
         return (2 * e['fetch_KB'] + e['write_KB']) * 1024.0
     except (OSError, KeyError, ValueError, StopIteration, TypeError):
-        pass
-    if B != 512:
-        return None
-    try:    # passes over tools/bench_lattice.py (same shapes, kernel alone)
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_lattice_fetch_write.json')))
-        return (2 * pmc['FETCH_SIZE'][k]['mean_KB'] + pmc['WRITE_SIZE'][k]['mean_KB']) * 1024.0
-    except (OSError, KeyError, ValueError):
         return None
 
 
@@ -554,7 +549,8 @@ def main():
             del feats_d
             torch.cuda.empty_cache()
             progress('bi-char numerator roofline launch')
-            res['roofline_bichar'] = bichar_numerator_roofline(dev)
+            res['roofline_bichar'] = bichar_numerator_roofline(
+                dev, traffic=pmc_traffic(2, B, T, 'lattice_fwbw_sl_kernel<3, 8, 0>'))
             torch.cuda.empty_cache()
             progress('stage-2 decode rate')
             res['decode'] = tcn_decode_rate(dev)
