@@ -7,6 +7,7 @@ torch.  There is NO CPU or eager fallback: a missing library or a non-GPU tensor
 raises immediately.
 """
 import ctypes
+import warnings
 import os
 
 import torch
@@ -22,6 +23,7 @@ _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
 # around every lattice forward-backward call (launched on the current stream)
 EVENT_HOOK = None
+_WARNED = {}
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -168,6 +170,11 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
     logZ = torch.empty(B, dtype=torch.float32, device=lp.device)
     grad = torch.empty_like(lp)
     zb = torch.empty(B, dtype=torch.float32, device=lp.device) if want_bwd_total else None
+    if T * B * C * 4 >= 2 ** 31 and graph.N <= 512 and not _WARNED.get('fits32'):
+        _WARNED['fits32'] = True        # csrc/lattice.hip: 32-bit buffer offsets in the fast kernels
+        warnings.warn('lattice_fwbw: T*B*C*4 = %.2f GiB >= 2 GiB (e.g. bi-char CTC at B >= ~670): the '
+                      'meet-in-the-middle kernels address with 32-bit offsets, this call runs the '
+                      'generic (much slower) kernel; split the batch' % (T * B * C * 4 / 2.0 ** 30))
     nbytes = L.asr_lattice_fwbw_workspace_bytes(T, B, C, graph.N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=lp.device)
     hook = EVENT_HOOK
