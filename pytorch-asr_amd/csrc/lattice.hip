@@ -561,6 +561,31 @@ __device__ __forceinline__ float seg_add(float v, float mask) {
     return fmaf(__builtin_bit_cast(float, y), mask, v);
 }
 
+// the six steps of the segmented scan as v_fmac_f32 with a DPP source operand (hipcc emits
+// v_mov_b32_dpp + v_fmac_f32 and a zeroing v_mov for the broadcasts: 17 instructions; here
+// 6 + the wait states a DPP read of a just-written VGPR needs).  Lanes without a source
+// (row start, rows a broadcast does not reach) are not written, i.e. add nothing.
+__device__ __forceinline__ float seg_scan6(float v, float m1, float m2, float m4, float m8,
+                                           float mb15, float mb31) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v)
+        : "v"(m1), "v"(m2), "v"(m4), "v"(m8), "v"(mb15), "v"(mb31));
+    return v;
+}
+
 #ifdef ASR_SL_NOBAR
 #define SL_BARRIER() do {} while (0)
 #else
@@ -776,13 +801,8 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
     // because it keeps the lgkmcnt waits counted).
     auto side_accumulate = [&]() {
         if (FL == 1) {
-            float v = gprev;
-            v = seg_add<0x111, 0xF>(v, m1);           // row_shr:1
-            v = seg_add<0x112, 0xF>(v, m2);           // row_shr:2
-            v = seg_add<0x114, 0xF>(v, m4);           // row_shr:4
-            v = seg_add<0x118, 0xF>(v, m8);           // row_shr:8
-            v = seg_add<0x142, 0xA>(v, mb15);         // row_bcast:15 -> rows 1, 3
-            v = seg_add<0x143, 0xC>(v, mb31);         // row_bcast:31 -> rows 2, 3
+            // row_shr:1, 2, 4, 8, then row_bcast:15 -> rows 1, 3 and row_bcast:31 -> rows 2, 3
+            const float v = seg_scan6(gprev, m1, m2, m4, m8, mb15, mb31);
             float *rw = row + ra + label;
             *(seg_plain ? rw : ldump) = v;
             if (seg_multi) atomicAdd(rw, v);
@@ -822,9 +842,9 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
         float mx = x[0];
 #pragma unroll
         for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k]);
-        float sum = 0.f;
+        float sum = __builtin_amdgcn_exp2f(x[0] - mx);
 #pragma unroll
-        for (int k = 0; k < K; ++k) sum += __builtin_amdgcn_exp2f(x[k] - mx);
+        for (int k = 1; k < K; ++k) sum += __builtin_amdgcn_exp2f(x[k] - mx);
         float val0 = mx + __builtin_amdgcn_logf(sum);     // B: beta_t
         float val1 = fmaf(ev, ASR_L2E, val0);             // A: alpha_{t+1}; B: beta_t + lp_{t-1}
         if (SOLO != 0) {
