@@ -839,12 +839,22 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) x[k] += r_w[k];
-        float mx = x[0];
+        float mx, sum;
+        if constexpr (K == 3 && FL == 1) {        // (C > H is bandwidth-bound: measured slower there)
+            // the largest term contributes exp2(0) = 1: sort (max3 / med3 / min3) and take two
+            // quarter-rate exponentials instead of three
+            mx = __builtin_fmaxf(__builtin_fmaxf(x[0], x[1]), x[2]);
+            const float md = __builtin_amdgcn_fmed3f(x[0], x[1], x[2]);
+            const float mn = __builtin_fminf(__builtin_fminf(x[0], x[1]), x[2]);
+            sum = 1.f + __builtin_amdgcn_exp2f(md - mx) + __builtin_amdgcn_exp2f(mn - mx);
+        } else {
+            mx = x[0];
 #pragma unroll
-        for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k]);
-        float sum = __builtin_amdgcn_exp2f(x[0] - mx);
+            for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k]);
+            sum = __builtin_amdgcn_exp2f(x[0] - mx);
 #pragma unroll
-        for (int k = 1; k < K; ++k) sum += __builtin_amdgcn_exp2f(x[k] - mx);
+            for (int k = 1; k < K; ++k) sum += __builtin_amdgcn_exp2f(x[k] - mx);
+        }
         float val0 = mx + __builtin_amdgcn_logf(sum);     // B: beta_t
         float val1 = fmaf(ev, ASR_L2E, val0);             // A: alpha_{t+1}; B: beta_t + lp_{t-1}
         if (SOLO != 0) {
