@@ -26,6 +26,43 @@ constexpr int KS = 7;             // kernel size (both axes)
 constexpr int PIX = 80;           // bytes per pixel in LDS
 constexpr int KSTEPS = KS * KS * CH / 16;      // 98 MFMA k-steps of 16
 
+// LDS row pitch (bytes) of a staged image whose MFMA tiles take 32 consecutive pixels of rows
+// `per_row` pixels long, `step` image rows apart: the pitch >= min_pitch (multiple of 16, at
+// most 256 bytes more) with the fewest ds_read_b128 bank conflicts over the first `ntiles`
+// tiles.  ds_read_b128 serves the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) of a
+// wave in one LDS cycle each when their 16 x 16 bytes fall into 64 distinct banks
+// (MI355X_MICROARCH.md, LDS): a plain pitch of per_row * 80 bytes costs 2x on these shapes
+// (rocprofv3: SQ_LDS_BANK_CONFLICT = 41 % of SQ_LDS_IDX_ACTIVE), the picked one 1x.
+inline int pick_row_pitch(int min_pitch, int per_row, int step, int npix, int ntiles) {
+    static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                   {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    int best = min_pitch, best_cost = 1 << 30;
+    for (int P = min_pitch; P <= min_pitch + 256; P += 16) {
+        int cost = 0;
+        for (int tile = 0; tile < ntiles; ++tile)
+            for (int g = 0; g < 2; ++g) {
+                int addr_of_bank[64], worst = 1, cnt[64];
+                for (int b = 0; b < 64; ++b) { addr_of_bank[b] = -1; cnt[b] = 0; }
+                for (int i = 0; i < 16; ++i) {
+                    int m = 32 * tile + grp[g][i];
+                    if (m >= npix) m = npix - 1;
+                    const int r = m / per_row, w = m - r * per_row;
+                    const int a = r * step * P + w * PIX;
+                    for (int k = 0; k < 4; ++k) {
+                        const int b = (a / 4 + k) & 63;
+                        if (addr_of_bank[b] != a + 4 * k) {         // a new address on this bank
+                            addr_of_bank[b] = a + 4 * k;
+                            if (++cnt[b] > worst) worst = cnt[b];
+                        }
+                    }
+                }
+                cost += worst;
+            }
+        if (cost < best_cost) { best_cost = cost; best = P; }
+    }
+    return best;
+}
+
 // ---- per-channel statistics of an output image in LDS -------------------------------------
 // oimg [npix][32] bf16 -> partial[64] = (sum over pixels, sum of squares) per channel, by
 // 256 threads (8 pixel groups x 32 channels); `red` = 512 floats of LDS scratch
@@ -83,17 +120,18 @@ struct ConvFwdParams {
     __bf16 *y;
     float *stats;                 // [workgroups][64] channel sums of the outputs, or null
     int B, H, W, Ho, Wo, R;       // R output rows per workgroup (R * Wo <= 192)
+    int pitch;                    // bytes per image row in LDS (pick_row_pitch)
 };
 
 // one k-half (49 k-steps) of the product for 3 M-tiles
 template <int SH, int KH>
-__device__ __forceinline__ void conv_fwd_half(const char *img, const unsigned (&pixbase)[3], int W,
+__device__ __forceinline__ void conv_fwd_half(const char *img, const unsigned (&pixbase)[3], int pitch,
                                               const bf16x8 (&bf)[49], f32x16 (&acc)[3]) {
 #pragma unroll
     for (int s = 0; s < 49; ++s) {
         const int ks = 49 * KH + s;
         const int kt = ks / 14, rem = ks % 14, kf = rem >> 1, cp = rem & 1;
-        const unsigned off = (unsigned)((kt * W + kf) * PIX + cp * 32);
+        const unsigned off = (unsigned)(kt * pitch + kf * PIX + cp * 32);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(img + pixbase[i] + off);
@@ -130,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
             u32x4 v = {0u, 0u, 0u, 0u};
             if (h0 + row < p.H)
                 v = *reinterpret_cast<const u32x4 *>(xb + ((size_t)(h0 + row) * W * 64 + (size_t)(pix - row * W) * 64 + part * 16));
-            *reinterpret_cast<u32x4 *>(smem + pix * PIX + part * 16) = v;
+            *reinterpret_cast<u32x4 *>(smem + row * p.pitch + (pix - row * W) * PIX + part * 16) = v;
         }
     }
     // ---- per-lane pixel bases of this wave's three M-tiles -------------------------------------
@@ -141,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
         int m = 32 * (3 * mh + i) + (lane & 31);
         if (m >= npix) m = npix - 1;                            // computed, never stored
         const int r = m / Wo, wo = m - r * Wo;
-        pixbase[i] = (unsigned)(((r * SH) * W + wo) * PIX + (lane >> 5) * 16);
+        pixbase[i] = (unsigned)((r * SH) * p.pitch + wo * PIX + (lane >> 5) * 16);
     }
     __syncthreads();
     f32x16 acc[3];
@@ -149,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-    if (kh == 0) conv_fwd_half<SH, 0>(smem, pixbase, W, bf, acc);
-    else conv_fwd_half<SH, 1>(smem, pixbase, W, bf, acc);
+    if (kh == 0) conv_fwd_half<SH, 0>(smem, pixbase, p.pitch, bf, acc);
+    else conv_fwd_half<SH, 1>(smem, pixbase, p.pitch, bf, acc);
     __syncthreads();                                            // image no longer needed
 
     // ---- sum the two k-halves, convert, write [pixel][co] rows to LDS, copy out coalesced -----
@@ -211,17 +249,18 @@ struct ConvDgradParams {
     const __bf16 *wpack;
     __bf16 *dx;
     int B, H, W, Ho, Wo, Rq;      // Rq rows q per workgroup and class (Rq * W <= 192)
+    int pitch;                    // bytes per (padded) dy row in LDS (pick_row_pitch)
 };
 
 // NS k-steps starting at class-local step S0 (class row count J = 3 for r = 0, else 2)
 template <int NS, int S0>
-__device__ __forceinline__ void conv_dgrad_part(const char *img, const unsigned (&pixbase)[6], int Wp,
+__device__ __forceinline__ void conv_dgrad_part(const char *img, const unsigned (&pixbase)[6], int pitch,
                                                 const bf16x8 *bf, f32x16 (&acc)[6]) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int sl = S0 + s;
         const int j = sl / 14, rem = sl % 14, kf = rem >> 1, cp = rem & 1;
-        const unsigned off = (unsigned)(((2 - j) * Wp + (6 - kf)) * PIX + cp * 32);
+        const unsigned off = (unsigned)((2 - j) * pitch + (6 - kf) * PIX + cp * 32);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(img + pixbase[i] + off);
@@ -258,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradPa
             u32x4 v = {0u, 0u, 0u, 0u};
             if (ho >= 0 && ho < p.Ho && wo >= 0 && wo < Wo)
                 v = *reinterpret_cast<const u32x4 *>(yb + ((size_t)ho * Wo + wo) * 64 + part * 16);
-            *reinterpret_cast<u32x4 *>(smem + pix * PIX + part * 16) = v;
+            *reinterpret_cast<u32x4 *>(smem + row * p.pitch + col * PIX + part * 16) = v;
         }
     }
     unsigned pixbase[6];
@@ -268,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradPa
         int m = 32 * i + (lane & 31);
         if (m >= npix) m = npix - 1;
         const int q = m / W, w = m - q * W;
-        pixbase[i] = (unsigned)((q * Wp + w) * PIX + (lane >> 5) * 16);
+        pixbase[i] = (unsigned)(q * p.pitch + w * PIX + (lane >> 5) * 16);
     }
     __syncthreads();
     f32x16 acc[6];
@@ -276,9 +315,9 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradPa
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-    if (wave == 0) conv_dgrad_part<21, 0>(smem, pixbase, Wp, bf, acc);
-    else if (wave == 1) conv_dgrad_part<21, 21>(smem, pixbase, Wp, bf, acc);
-    else conv_dgrad_part<28, 0>(smem, pixbase, Wp, bf, acc);
+    if (wave == 0) conv_dgrad_part<21, 0>(smem, pixbase, p.pitch, bf, acc);
+    else if (wave == 1) conv_dgrad_part<21, 21>(smem, pixbase, p.pitch, bf, acc);
+    else conv_dgrad_part<28, 0>(smem, pixbase, p.pitch, bf, acc);
     __syncthreads();
 
     // ---- epilogue: wave 1 -> wave 0 partial sum; [class][pixel][ci] bf16 image; coalesced rows ----
@@ -662,7 +701,8 @@ extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int
     if (Wo > 48) return ASR_EUNSUPPORTED;
     int R = 192 / Wo;
     if (R > 16) R = 16;
-    const size_t img = (size_t)(stride_h * (R - 1) + KS) * W * PIX;
+    const int pitch = pick_row_pitch(W * PIX, Wo, stride_h, R * Wo, 6);
+    const size_t img = (size_t)(stride_h * (R - 1) + KS) * pitch;
     const size_t epi = (size_t)2 * 3 * 16 * 64 * 4 + (size_t)192 * CH * 2;
     const size_t lds = img > epi ? img : epi;
     if (lds > 80 * 1024) return ASR_EUNSUPPORTED;
@@ -671,7 +711,7 @@ extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int
     hipLaunchKernelGGL(conv_pack_fwd_kernel, dim3((KSTEPS * 64 * 8 + 255) / 256), dim3(256), 0, s, w, wpack);
     ConvFwdParams p;
     p.x = (const __bf16 *)x; p.wpack = wpack; p.y = (__bf16 *)y;
-    p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.R = R;
+    p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.R = R; p.pitch = pitch;
     const dim3 grid((Ho + R - 1) / R, B);
     // the weight gradient's partial-sum area doubles as the statistics' (never live together)
     p.stats = chan_sums ? (float *)((char *)workspace + (size_t)KSTEPS * 64 * 8 * 2 * 2) : nullptr;
@@ -699,7 +739,8 @@ extern "C" int asr_conv7x7c32_bwd_data_bf16(const void *dy, const float *w, int 
     if (W > 48) return ASR_EUNSUPPORTED;
     int Rq = 192 / W;
     if (Rq > 16) Rq = 16;
-    const size_t img = (size_t)(Rq + 2) * (Wo + 12) * PIX;
+    const int pitch = pick_row_pitch((Wo + 12) * PIX, W, 1, Rq * W, 6);
+    const size_t img = (size_t)(Rq + 2) * pitch;
     const size_t epi = (size_t)6 * 16 * 64 * 4 + (size_t)3 * 192 * CH * 2;
     const size_t lds = img > epi ? img : epi;
     if (lds > 80 * 1024) return ASR_EUNSUPPORTED;
@@ -708,7 +749,7 @@ extern "C" int asr_conv7x7c32_bwd_data_bf16(const void *dy, const float *w, int 
     hipLaunchKernelGGL(conv_pack_dgrad_kernel, dim3((KSTEPS * 64 * 8 + 255) / 256), dim3(256), 0, s, w, wpack);
     ConvDgradParams p;
     p.dy = (const __bf16 *)dy; p.wpack = wpack; p.dx = (__bf16 *)dx;
-    p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Rq = Rq;
+    p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Rq = Rq; p.pitch = pitch;
     const int nq = (H + 2) / 3;                                  // q = 0 .. ceil(H / 3) - 1
     const dim3 grid((nq + Rq - 1) / Rq, B);
     if (lds > 64 * 1024 &&
