@@ -22,6 +22,22 @@ def _mm_f32(a, b):
         return torch.mm(a, b).float()
 
 
+def _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, want_y):
+    """One layer's recurrence from its bf16 input [T*B, F].  With F == H the input
+    projection runs inside the persistent kernel (asr_lstm_bidir_fwd_fused_bf16: no
+    [T*B, 8H] product in HBM; ASR_LSTM_FUSED=0 restores the GEMM); otherwise x·W_ih is one
+    GEMM, accumulated in fp32 and stored once as bf16 (ASR_GX_FP32=1 keeps fp32: the
+    product is 1.75 GB in fp32 at B=512 and its write bounds the GEMM)."""
+    if (xb.shape[1] == H and os.environ.get('ASR_LSTM_FUSED', '1') != '0'
+            and _native.lstm_fused_supported(B, H)):
+        return _native.lstm_bidir_fwd_fused(xb.view(T, B, H), w_ih, whh, lens_dev, want_y=want_y)
+    if os.environ.get('ASR_GX_FP32', '0') == '1':
+        gx = _mm_f32(xb, w_ih.t()).view(T, B, 2, 4 * H)
+    else:
+        gx = torch.mm(xb, w_ih.t()).view(T, B, 2, 4 * H)
+    return _native.lstm_bidir_fwd(gx, whh, lens_dev, want_y=want_y)
+
+
 def _chunks(n, target):
     """largest power of two <= target that divides n and leaves >= 2048 rows per chunk"""
     g = target
@@ -48,14 +64,8 @@ class BiLSTMFunction(torch.autograd.Function):
         H = w_hh_f.shape[1]
         xb = x.reshape(T * B, F).to(torch.bfloat16)
         w_ih = torch.cat([w_ih_f, w_ih_r], 0).to(torch.bfloat16)        # [2*4H, F]
-        # x·W_ih: fp32 accumulation in the GEMM, stored once as bf16 (ASR_GX_FP32=1 keeps
-        # fp32): the [T*B, 8H] product is 1.75 GB in fp32 at B=512 and its write bounds the GEMM
-        if os.environ.get('ASR_GX_FP32', '0') == '1':
-            gx = _mm_f32(xb, w_ih.t()).view(T, B, 2, 4 * H)
-        else:
-            gx = torch.mm(xb, w_ih.t()).view(T, B, 2, 4 * H)
         whh = torch.stack([w_hh_f, w_hh_r], 0).to(torch.bfloat16).contiguous()
-        y, ybf, gates, csave = _native.lstm_bidir_fwd(gx, whh, lens_dev)
+        y, ybf, gates, csave = _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, True)
         ctx.save_for_backward(xb, lens_dev, w_ih, whh, ybf, gates, csave)
         return y.sum(2) if sum_dirs else y
 
@@ -122,10 +132,9 @@ class BiLSTMStackFunction(torch.autograd.Function):
             w_ih_f, w_hh_f, w_ih_r, w_hh_r = weights[4 * l:4 * l + 4]
             H = w_hh_f.shape[1]
             w_ih = torch.cat([w_ih_f, w_ih_r], 0).to(torch.bfloat16)
-            gx = torch.mm(xb, w_ih.t()).view(T, B, 2, 4 * H)
             whh = torch.stack([w_hh_f, w_hh_r], 0).to(torch.bfloat16).contiguous()
             last = l == n - 1
-            y, ybf, gates, csave = _native.lstm_bidir_fwd(gx, whh, lens_dev, want_y=last)
+            y, ybf, gates, csave = _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, last)
             saved += [xb, w_ih, whh, ybf, gates, csave]
             if not last:
                 xb = (ybf[0, 1:T + 1] + ybf[1, 1:T + 1]).view(T * B, H)

@@ -114,6 +114,8 @@ __device__ __forceinline__ float load_gx(const void *gx, size_t i) {
 struct LstmFwdParams {
     const void *gx;         // [T,B,2,4H] x·W_ihᵀ, gate order i,f,g,o; float or (gx_bf16) __bf16
     int gx_bf16;
+    const __bf16 *x;        // fused input projection (persistent kernel, F == H): x [T,B,H] bf16 row-major
+    const __bf16 *wih;      // ... and the fragment-major pack of W_ih [2*4 (dir,gate)][H rows][H cols]
     const __bf16 *whh;      // fragment-major pack of [2*4 (dir,gate)][H rows][H cols]
     const int32_t *lens;    // [B]
     int T, B, H;
@@ -460,6 +462,32 @@ __device__ __forceinline__ bool team_wait(unsigned *ctr, unsigned target, unsign
 #define PSTAMP(i) do {} while (0)
 #endif
 
+// LDS-DMA: 64 lanes x 16 bytes from a bounds-checked raw buffer straight to LDS at
+// `lds_byte` + lane * 16 (out-of-range lanes write zeros).  Inline asm: hipcc would order
+// every later LDS read behind it with s_waitcnt vmcnt(0) (cdna_hip_programming.md §5.7);
+// the kernel waits where it needs the data.
+typedef __attribute__((ext_vector_type(4))) int rsrc_words;
+__device__ __forceinline__ rsrc_words raw_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    rsrc_words r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((unsigned)(a >> 32) & 0xffffu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void dma16_s(rsrc_words r, unsigned lds_byte, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_byte), "v"(voff), "s"(r), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *ptr) {
+    return (unsigned)(size_t)((__attribute__((address_space(3))) const void *)ptr);
+}
+
 struct LstmTeamCtl {
     unsigned *ctr;          // [2 dir][nbt] counters, 32 words (128 B) apart, zeroed per call
     unsigned *err;          // timeout word
@@ -474,12 +502,21 @@ struct LstmTeamCtl {
 // NE = batch rows of the tile / 8 (tiles of 16, 24 or 32 rows: fewer rows per workgroup
 // = more workgroups; the host picks the smallest tile whose grid still fits one
 // workgroup per CU).  Rows >= 8*NE of the 32-row MFMA tile are padding.
-template <int KS, int NE, int GXB>
+//
+// XF = 1 fuses the input projection: instead of reading x·W_ihᵀ (`gx`, the output of a
+// [T·B, F] x [F, 8H] library GEMM: 0.37 ms and 2 GB of HBM traffic per layer at B=576) the
+// workgroup keeps its W_ih slice in registers next to W_hh (F == H) and multiplies the x_t
+// tile itself — x_t does not depend on the recurrence, so waves 4-7 do it while the
+// workgroup waits for the team's counter and waves 0-3 while the hand-off tile is in
+// flight: both windows (911 / 1036 cycles at B=512) were idle.  The sum x_t·W_ih + h·W_hh
+// is accumulated in fp32 in one MFMA chain (the bf16 rounding of `gx` is gone).
+template <int KS, int NE, int GXB, int XF>
 __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, LstmTeamCtl ctl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *a_lds = reinterpret_cast<__bf16 *>(smem);                       // KS KiB
     float (*g_lds)[32][65] = reinterpret_cast<float (*)[32][65]>(smem + KS * 1024);
     __bf16 *h_lds = reinterpret_cast<__bf16 *>(smem + KS * 1024 + ASR_GLDS_BYTES);   // 4 KiB
+    __bf16 *x_lds = reinterpret_cast<__bf16 *>(smem + KS * 1024 + ASR_GLDS_BYTES + 4096);   // XF: KS KiB
     __shared__ int dead_s;
     const int H = p.H, B = p.B, T = p.T;
     int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
@@ -503,13 +540,19 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     for (int i = tid; i < 2048; i += 512) h_lds[i] = (__bf16)0.f;       // padding rows stay 0
     for (int i = tid; i < KS * 64; i += 512)                            // (the tile's too: never loaded)
         reinterpret_cast<u32x4 *>(a_lds)[i] = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (XF)
+        for (int i = tid; i < KS * 64; i += 512)
+            reinterpret_cast<u32x4 *>(x_lds)[i] = u32x4{0u, 0u, 0u, 0u};
 
-    bf16x8 fb[KS];
+    bf16x8 fb[KS], fx[XF ? KS : 1];
     {
-        const __bf16 *bp = p.whh + ((size_t)(dir * 4 + gate) * H * H) +
-                           ((size_t)(2 * jt + js) * KS * 64 + lane) * 8;
+        const size_t wo = ((size_t)(dir * 4 + gate) * H * H) + ((size_t)(2 * jt + js) * KS * 64 + lane) * 8;
 #pragma unroll
-        for (int k = 0; k < KS; ++k) fb[k] = *reinterpret_cast<const bf16x8 *>(bp + k * 512);
+        for (int k = 0; k < KS; ++k) fb[k] = *reinterpret_cast<const bf16x8 *>(p.whh + wo + k * 512);
+        if constexpr (XF) {
+#pragma unroll
+            for (int k = 0; k < KS; ++k) fx[k] = *reinterpret_cast<const bf16x8 *>(p.wih + wo + k * 512);
+        }
     }
     const __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc(
         p.hbuf, 0, (int)(2 * 2 * Bp * H * 2), 0x00020000);
@@ -526,7 +569,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     typedef unsigned int u32;
     constexpr u32 OOBV = 0xFFFFFFFFu;
     constexpr u32 GXE = GXB ? 2u : 4u;
-    u32 vgx[NE], vy[NE], vyb[NE], vcs[NE], vg[NE];
+    u32 vgx[NE], vy[NE], vyb[NE], vcs[NE];     // gate records: 2 * vcs
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int b = b0 + e * 8 + wave;
@@ -538,12 +581,31 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         vy[e] = b < B ? (u32)((b * 2 + dir) * H + j) * 4u : OOBV;
         vyb[e] = b < B ? (u32)(((size_t)(dir * (T + 2) + 1) * B + b) * H + j) * 2u : OOBV;
         vcs[e] = b < B ? (u32)((dir * B + b) * H + j) * 4u : OOBV;
-        vg[e] = b < B ? (u32)((dir * B + b) * H + j) * 8u : OOBV;
     }
     const u32 fgx = (u32)B * 8u * H * GXE, fy = (u32)B * 2u * H * 4u, fyb = (u32)B * H * 2u;
     const u32 fcs = (u32)B * 2u * H * 4u, fg = (u32)B * 2u * H * 8u;
     const __amdgpu_buffer_rsrc_t gxR = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void *>(p.gx), 0, (int)((u32)T * fgx), 0x00020000);
+        const_cast<void *>(p.gx), 0, XF ? 0 : (int)((u32)T * fgx), 0x00020000);
+    // XF: the x_t tile goes global -> LDS by LDS-DMA, no registers: the 1 KiB A fragment of
+    // k-step k is lane-linear in LDS (lane = row + 32 * k-half, 16 bytes each), which is
+    // exactly the destination pattern of one `buffer_load_dwordx4 ... lds`; lanes of the
+    // tile's padding rows carry an out-of-range offset and write zeros.  Wave w moves
+    // k-steps w, w + 8, w + 16.
+    const rsrc_words xD = raw_rsrc(p.x, XF ? (unsigned)((u32)T * B * H * 2u) : 0u);
+    const u32 fx_frame = (u32)B * H * 2u;
+    u32 vx = 0x80000000u;
+    if constexpr (XF) {
+        const int xr = lane & 31, b = b0 + xr < B ? b0 + xr : B - 1;
+        if (xr < 8 * NE) vx = (u32)(b * H + 16 * wave + 8 * (lane >> 5)) * 2u;
+    }
+    auto x_dma = [&](int tq) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (wave + 8 * i < KS)
+                dma16_s(xD, (unsigned)__builtin_amdgcn_readfirstlane(
+                                (int)(lds_addr(x_lds) + (unsigned)(wave + 8 * i) * 1024u)),
+                        vx + (u32)i * 256u, (u32)__builtin_amdgcn_readfirstlane((int)((u32)tq * fx_frame)));
+    };
     // y == null: zero records, every fp32 output store is dropped by the bounds check
     const __amdgpu_buffer_rsrc_t yR = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y ? (int)((u32)T * fy) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ybR = __builtin_amdgcn_make_buffer_rsrc(
@@ -561,14 +623,30 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     // (behind the hand-off tile in the wave's in-order vmcnt queue, never in
     // front of the team poll); the outputs nobody inside the launch reads are
     // stored after the team signal, under the hand-off latency.
-    float pgx[NE][4];
+    float pgx[XF ? 1 : NE][4];
     {
         const int t0 = dir == 0 ? 0 : T - 1;
+        if constexpr (XF) {
+            __syncthreads();            // the zero fill above
+            x_dma(t0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
 #pragma unroll
-        for (int e = 0; e < NE; ++e)
+            for (int e = 0; e < NE; ++e)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pgx[e][g] = ld_gx(vgx[e], (u32)t0 * fgx + (u32)g * H * GXE);
+                for (int g = 0; g < 4; ++g) pgx[e][g] = ld_gx(vgx[e], (u32)t0 * fgx + (u32)g * H * GXE);
+        }
     }
+    f32x16 accx;                 // XF: x_t · W_ih of this wave's (gate, column half)
+    auto x_mfma = [&]() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accx[i] = 0.f;
+        const bf16x8 *xl = reinterpret_cast<const bf16x8 *>(x_lds) + lane;
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[k * 64], fx[XF ? k : 0], accx, 0, 0, 0);
+    };
     float sog[NE][4] = {}, soh[NE] = {}, sc[NE] = {};
     bool sact[NE] = {};
     int st = 0;
@@ -586,13 +664,29 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sc[e]), csR,
                                                   live ? vcs[e] : OOBV, ust * fcs, 0);
             __builtin_amdgcn_raw_buffer_store_b64(pack_gates(sog[e]), gR,
-                                                  live && sact[e] ? vg[e] : OOBV, ust * fg, 0);
+                                                  live && sact[e] ? vcs[e] * 2u : OOBV, ust * fg, 0);
         }
     };
 
+    if constexpr (XF) {
+        // Everything the prologue loaded must have landed BEFORE the loop: the compiler does
+        // not see the LDS-DMA inside the asm, so a wait it places inside the loop for one of
+        // these (first use of a weight fragment / a length) is counted without them and
+        // degenerates to vmcnt(0) right behind the x_{t+1} DMA — the MFMA phase then waits
+        // for the DMA (measured: 1992 -> 4091 cycles).  Naming the registers as asm operands
+        // makes it wait here.
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            asm volatile("" : "+v"(fb[k]));
+            asm volatile("" : "+v"(fx[k]));
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) asm volatile("" : "+v"(len[e]));
+    }
     PSTAMP_DECL;
     for (int step = 0; step < T; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
+        if constexpr (XF) if (wave >= 4) x_mfma();          // under the team wait
         if (step > 0 && tid == 0 && !dead_s) {
             if (!team_wait(myctr, (unsigned)(njt * step), ctl.spin_limit, ctl.err)) dead_s = 1;
         }
@@ -621,7 +715,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         if (tid < 256)
             reinterpret_cast<u32x4 *>(a_lds)[(4 * jt + (tid >> 6)) * 64 + (tid & 63)] =
                 reinterpret_cast<const u32x4 *>(h_lds)[tid];
+        if constexpr (XF) if (wave < 4) x_mfma();           // under the hand-off tile's flight
         if constexpr (NI > 0) {
+            // (XF: wait for the tile on every path, not only inside the `co < CHO` branch —
+            // otherwise the compiler protects the MFMA accumulators that reuse these
+            // registers with a vmcnt(0) placed behind the x_{t+1} DMA it cannot see)
+            if constexpr (XF) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(tmp[i]));
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int co = i * 512 + tid;
@@ -632,20 +734,31 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         }
         __syncthreads();
         PSTAMP(1);
-        float ngx[NE][4];
+        float ngx[XF ? 1 : NE][4];
         {
             const int sn = step + 1 < T ? step + 1 : step;
             const int tn = dir == 0 ? sn : T - 1 - sn;
+            if constexpr (XF) {
+                // x_{t+1}: every read of x_lds for this step lies before the tile barrier above;
+                // landed at the s_waitcnt vmcnt(0) in front of the signal barrier below
+                // (32-row tiles keep two weight fragments in scratch; their reloads inside the
+                // MFMA loop would wait for this DMA: issued behind the loop there)
+                if constexpr (NE < 4) x_dma(tn);
+            } else {
 #pragma unroll
-            for (int e = 0; e < NE; ++e)
+                for (int e = 0; e < NE; ++e)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    ngx[e][g] = ld_gx(vgx[e], (u32)tn * fgx + (u32)g * H * GXE);
+                    for (int g = 0; g < 4; ++g)
+                        ngx[e][g] = ld_gx(vgx[e], (u32)tn * fgx + (u32)g * H * GXE);
+            }
         }
         {
             f32x16 acc;
+            if constexpr (XF) acc = accx;
+            else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            }
             const bf16x8 *al = reinterpret_cast<const bf16x8 *>(a_lds) + lane;
 #pragma unroll
             for (int k = 0; k < KS; ++k)
@@ -656,6 +769,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                 g_lds[gate][row][js * 32 + c32] = acc[i];
             }
+        }
+        if constexpr (XF && NE == 4) {
+            const int sn = step + 1 < T ? step + 1 : step;
+            x_dma(dir == 0 ? sn : T - 1 - sn);
         }
         __syncthreads();
         PSTAMP(2);
@@ -668,7 +785,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
             if (sact[e]) {
                 float pre[4], cn;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pre[g] = g_lds[g][row][col] + pgx[e][g];
+                for (int g = 0; g < 4; ++g) pre[g] = XF ? g_lds[g][row][col] : g_lds[g][row][col] + pgx[XF ? 0 : e][g];
                 lstm_cell_fwd(pre, c[e], sog[e], cn, soh[e]);
                 c[e] = cn;
                 if (dead) soh[e] = __builtin_nanf("");
@@ -697,10 +814,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         // NEXT step's tile loads instead, as the backward kernel does, was measured 1 % slower
         // here: 28 KB of stores in the window of the tile loads.)
         bulk_store(true);
+        if constexpr (!XF) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e)
+            for (int e = 0; e < NE; ++e)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pgx[e][g] = ngx[e][g];
+                for (int g = 0; g < 4; ++g) pgx[e][g] = ngx[e][g];
+        }
         PSTAMP(5);
     }
 #ifdef ASR_LSTM_STAMPS
@@ -1038,8 +1157,16 @@ extern "C" int64_t asr_lstm_workspace_bytes(int B, int H) {
     // backward: dgbuf bf16 [2][2][Bp][4H] + dcbuf f32 [2][B][H] + packed W_hhᵀ (larger)
     // + team counters of the persistent kernels: [2 dir][ceil(B/32)] x 128 B and a timeout word
     const int64_t Bp = plane_rows(B);
+    // (forward with the fused input projection: a second packed matrix, W_ih)
     return (int64_t)2 * 2 * Bp * 4 * H * 2 + (int64_t)2 * B * H * 4 +
-           (int64_t)2 * 4 * H * H * 2 + 256 + ctl_bytes(B);
+           (int64_t)2 * 2 * 4 * H * H * 2 + 256 + ctl_bytes(B);
+}
+
+namespace {
+int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *wih_bf16,
+                  const void *whh_bf16, const int32_t *lens, int T, int B, int H,
+                  float *y, void *y_bf16, void *gates_bf16, float *csave,
+                  void *workspace, int64_t workspace_bytes, uint32_t *err_flag, void *stream);
 }
 
 extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *whh_bf16,
@@ -1048,10 +1175,40 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
                                        float *csave,
                                        void *workspace, int64_t workspace_bytes,
                                        uint32_t *err_flag, void *stream) {
+    if (!gx) return ASR_EINVAL;
+    return lstm_fwd_impl(gx, gx_bf16, nullptr, nullptr, whh_bf16, lens, T, B, H, y, y_bf16,
+                         gates_bf16, csave, workspace, workspace_bytes, err_flag, stream);
+}
+
+extern "C" int asr_lstm_bidir_fwd_fused_bf16(const void *x_bf16, const void *wih_bf16,
+                                             const void *whh_bf16, const int32_t *lens,
+                                             int T, int B, int H, float *y, void *y_bf16,
+                                             void *gates_bf16, float *csave, void *workspace,
+                                             int64_t workspace_bytes, uint32_t *err_flag,
+                                             void *stream) {
+    if (!x_bf16 || !wih_bf16) return ASR_EINVAL;
+    return lstm_fwd_impl(nullptr, 1, x_bf16, wih_bf16, whh_bf16, lens, T, B, H, y, y_bf16,
+                         gates_bf16, csave, workspace, workspace_bytes, err_flag, stream);
+}
+
+extern "C" int asr_lstm_fused_supported(int B, int H) {
+    if (!persist_enabled() || B <= 0) return 0;
+    if (H != 64 && H != 128 && H != 256 && H != 320) return 0;
+    return cu_count() >= 2 * (H / 64) ? 1 : 0;
+}
+
+namespace {
+int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *wih_bf16,
+                  const void *whh_bf16, const int32_t *lens, int T, int B, int H,
+                  float *y, void *y_bf16, void *gates_bf16, float *csave,
+                  void *workspace, int64_t workspace_bytes, uint32_t *err_flag, void *stream) {
+    const bool fused = x_bf16 != nullptr;
     if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0) return ASR_EINVAL;
     if (T == 0) return ASR_OK;
-    if (!gx || !whh_bf16 || !lens || !y_bf16 || !gates_bf16 || !csave || !workspace)
+    if (!whh_bf16 || !lens || !y_bf16 || !gates_bf16 || !csave || !workspace)
         return ASR_EINVAL;
+    if (fused && (!asr_lstm_fused_supported(B, H) || (uint64_t)T * B * H * 2 >= (1ull << 31)))
+        return ASR_EUNSUPPORTED;
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmFwdParams p;
@@ -1059,6 +1216,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
     const size_t hbytes = (size_t)2 * 2 * Bp * H * 2, cbytes = (size_t)2 * B * H * 4;
     __bf16 *wpack = (__bf16 *)((char *)workspace + hbytes + cbytes);
     p.gx = gx; p.gx_bf16 = gx_bf16; p.whh = wpack; p.lens = lens;
+    p.x = (const __bf16 *)x_bf16; p.wih = wpack + (size_t)8 * H * H;
     p.T = T; p.B = B; p.H = H;
     p.hbuf = (__bf16 *)workspace;
     p.cbuf = (float *)((char *)workspace + hbytes);
@@ -1072,24 +1230,32 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
     // [2 dir x 4 gates] matrices of H x H (rows = hidden unit, cols = k)
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
                        (const __bf16 *)whh_bf16, wpack, 8, H, H, 0);
+    if (fused)          // wih_bf16: [2 dir][4H rows (gate-major)][H cols] row-major, F == H
+        hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
+                           (const __bf16 *)wih_bf16, wpack + (size_t)8 * H * H, 8, H, H, 0);
     if (persist_enabled()) {
         unsigned *ctl_words = (unsigned *)((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B));
         zero_async(ctl_words, (size_t)ctl_bytes(B), s);
         void (*pk[3])(LstmFwdParams, LstmTeamCtl) = {nullptr, nullptr, nullptr};
-#define ASR_PICK(KSV) if (H == 16 * KSV) {                                                     \
-        if (gx_bf16) { pk[0] = lstm_fwd_persist_kernel<KSV, 2, 1>; pk[1] = lstm_fwd_persist_kernel<KSV, 3, 1>; \
-                       pk[2] = lstm_fwd_persist_kernel<KSV, 4, 1>; }                                \
-        else { pk[0] = lstm_fwd_persist_kernel<KSV, 2, 0>; pk[1] = lstm_fwd_persist_kernel<KSV, 3, 0>; \
-               pk[2] = lstm_fwd_persist_kernel<KSV, 4, 0>; } }
+#define ASR_PICK(KSV) if (H == 16 * KSV && !fused) {                                           \
+        if (gx_bf16) { pk[0] = lstm_fwd_persist_kernel<KSV, 2, 1, 0>; pk[1] = lstm_fwd_persist_kernel<KSV, 3, 1, 0>; \
+                       pk[2] = lstm_fwd_persist_kernel<KSV, 4, 1, 0>; }                             \
+        else { pk[0] = lstm_fwd_persist_kernel<KSV, 2, 0, 0>; pk[1] = lstm_fwd_persist_kernel<KSV, 3, 0, 0>; \
+               pk[2] = lstm_fwd_persist_kernel<KSV, 4, 0, 0>; } }
         ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32)   // 48: W_hh slice spills
+#undef ASR_PICK
+#define ASR_PICK(KSV) if (H == 16 * KSV && fused) { pk[0] = lstm_fwd_persist_kernel<KSV, 2, 1, 1>; \
+        pk[1] = lstm_fwd_persist_kernel<KSV, 3, 1, 1>; pk[2] = lstm_fwd_persist_kernel<KSV, 4, 1, 1>; }
+        ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16)     // two weight slices in registers
 #undef ASR_PICK
         // the persistent kernel addresses gx / y / gates / ... with 32-bit byte offsets
         const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (1ull << 32) &&
                             (uint64_t)2 * (T + 2) * B * H * 2 < (1ull << 32);
-        if (fits32 && pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + ASR_GLDS_BYTES + 4096,
+        if (fits32 && pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 * (fused ? 2 : 1) + ASR_GLDS_BYTES + 4096,
                                  ctl_words, err_flag, s))
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
+    if (fused) return ASR_EUNSUPPORTED;
     // one launch per step.  64-row tiles (bt = 2) halve the W_hh re-reads but were
     // measured SLOWER (13.7 vs 11.4 us at B=512): the step is latency-bound per
     // workgroup, not fetch-bound
@@ -1107,6 +1273,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
     }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
+}  // namespace
 
 extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
                                        const int32_t *lens, int T, int B, int H,

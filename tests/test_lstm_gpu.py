@@ -122,6 +122,65 @@ def test_persistent_recurrence_is_bitwise_the_per_step_one(T, B, H, reps):
             assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
 
 
+@pytest.mark.parametrize('T,B,H,reps', [
+    (1, 1, 64, 1),
+    (23, 7, 64, 1),            # one workgroup per team, ragged batch tile
+    (61, 45, 128, 1),
+    (19, 70, 256, 1),
+    (150, 96, 320, 1),         # 16-row batch tiles
+    (334, 512, 320, 3),        # bench shape (24-row tiles), repeated
+    (40, 900, 320, 1),         # 32-row tiles in several launches
+])
+def test_fused_input_projection_matches_gemm_plus_recurrence(T, B, H, reps):
+    """asr_lstm_bidir_fwd_fused_bf16 (x_t·W_ih inside the persistent kernel, the tile brought
+    in by LDS-DMA under the hand-off waits) against the fp32 product of the same bf16
+    operands fed to asr_lstm_bidir_fwd_bf16.  Same arithmetic up to the order of the fp32
+    accumulation (the x term opens the MFMA chain instead of being added after it).  A
+    last-bit difference in a pre-activation can flip the bf16 rounding of an h_t that feeds
+    the next step, so over hundreds of steps the two runs drift by a few bf16 ulps of single
+    elements (measured 7e-4 at T=150; a stale tile would be O(1)): 5e-3 on the fp32 outputs,
+    2e-2 on the bf16 records; every repetition of the fused kernel is bit-identical to the first (a stale x tile
+    or a torn hand-off would change bits)."""
+    from att_speech import _native
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(T * 17 + B)
+    lens = torch.randint(1, T + 1, (B,), generator=g).sort(descending=True)[0]
+    lens[0] = T
+    x = torch.randn(T, B, H, generator=g).to(dev, torch.bfloat16)
+    wih = (torch.randn(8 * H, H, generator=g) * (1.0 / H ** 0.5)).to(dev, torch.bfloat16)
+    whh = (torch.randn(2, 4 * H, H, generator=g) * (1.0 / H ** 0.5)).to(dev, torch.bfloat16)
+    lens_d = lens.to(dev, torch.int32)
+    assert _native.lstm_fused_supported(B, H)
+    gx = torch.mm(x.view(T * B, H), wih.t(), out_dtype=torch.float32).view(T, B, 2, 4 * H)
+    ref = _native.lstm_bidir_fwd(gx, whh, lens_d)
+    act = (torch.arange(T)[:, None] < lens[None, :]).to(dev)
+    first = None
+    for _ in range(reps):
+        out = _native.lstm_bidir_fwd_fused(x, wih, whh, lens_d)
+        torch.cuda.synchronize()
+        _native.lstm_check_errors()
+        if first is None:
+            first = out
+            for name, a, b in zip(('y', 'y_bf16', 'gates', 'csave'), out, ref):
+                if name == 'gates':
+                    m = act[:, None, :, None, None].expand_as(a)
+                    a, b = a[m], b[m]
+                a, b = a.float(), b.float()
+                assert not torch.isnan(a).any(), name
+                tol = 2e-2 if name in ('y_bf16', 'gates') else 5e-3
+                err = float((a - b).abs().max()) if a.numel() else 0.0
+                assert err <= tol * (1.0 + float(b.abs().max()) if b.numel() else 1.0), (name, err)
+        else:
+            for name, a, b in zip(('y', 'y_bf16', 'gates', 'csave'), out, first):
+                if name == 'gates':
+                    m = act[:, None, :, None, None].expand_as(a)
+                    a, b = a[m], b[m]
+                assert torch.equal(a, b), name
+    # y == None: the inner layers of a stack ask for the bf16 plane only
+    out = _native.lstm_bidir_fwd_fused(x, wih, whh, lens_d, want_y=False)
+    assert out[0] is None and torch.equal(out[1], first[1])
+
+
 def test_handoff_timeout_surfaces_as_an_error(monkeypatch):
     """A persistent-recurrence hand-off whose spin bound expires poisons the outputs with
     NaN and sets the caller's error word; `_native.lstm_check_errors` (called once per step

@@ -24,8 +24,14 @@ whh = (torch.randn(2, 4 * H, H, device=dev) * 0.05).to(torch.bfloat16)
 lens = torch.full((B,), T, dtype=torch.int32, device=dev)
 dy = torch.randn(T, B, 2, H, device=dev)
 whhT = whh.view(2, 4 * H, H).transpose(1, 2).contiguous()
+FUSED = os.environ.get('FUSED', '0') == '1'      # stamps of the fused-input-projection kernel
+x = torch.randn(T, B, H, device=dev).to(torch.bfloat16)
+wih = (torch.randn(8 * H, H, device=dev) * 0.05).to(torch.bfloat16)
 for _ in range(3):
-    y, ybf, gates, cs = _native.lstm_bidir_fwd(gx, whh, lens)
+    if FUSED:
+        y, ybf, gates, cs = _native.lstm_bidir_fwd_fused(x, wih, whh, lens)
+    else:
+        y, ybf, gates, cs = _native.lstm_bidir_fwd(gx, whh, lens)
     dg = _native.lstm_bidir_bwd(dy, whhT, lens, gates, cs)
 torch.cuda.synchronize()
 R = int(os.environ.get('TILE_ROWS', '24'))    # batch rows per tile the host picked (24 at B=512)
