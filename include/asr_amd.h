@@ -244,15 +244,31 @@ int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *whh_bf16,
  *   wih_bf16  [2 dir][4H][H] bf16, rows in gate order i,f,g,o (nn.LSTM weight_ih_l0 /
  *             weight_ih_l0_reverse stacked)
  * Pre-activations are accumulated in fp32 over both products (no bf16 rounding of
- * x·W_ihᵀ).  ASR_EUNSUPPORTED when asr_lstm_fused_supported(B, H) == 0 (hidden size not
- * one of 64/128/256/320, persistent path switched off): the caller then uses the GEMM +
- * asr_lstm_bidir_fwd_bf16. */
+ * x·W_ihᵀ).  ASR_EUNSUPPORTED when bit 0 of asr_lstm_fused_supported(B, H) is clear (hidden
+ * size not one of 64/128/256/320, persistent path switched off): the caller then uses the
+ * GEMM + asr_lstm_bidir_fwd_bf16. */
 int asr_lstm_fused_supported(int B, int H);
 int asr_lstm_bidir_fwd_fused_bf16(const void *x_bf16, const void *wih_bf16,
                                   const void *whh_bf16, const int32_t *lens,
                                   int T, int B, int H, float *y, void *y_bf16,
                                   void *gates_bf16, float *csave, void *workspace,
                                   int64_t workspace_bytes, uint32_t *err_flag, void *stream);
+
+/* Backward recurrence with the input gradient fused (replaces the `dgates·W_ih` GEMM behind
+ * asr_lstm_bidir_bwd_bf16 when the layer's input size equals H):
+ *   wihT_bf16 [2 dir][H (input feature)][4H] bf16 — W_ih of each direction, transposed
+ *   dx        [2 dir][T,B,H] f32 out: dgates_dir · W_ih_dir; the layer's input gradient is
+ *             the sum of the two planes.  The layer below takes them as they are:
+ *   dy_shared = 2 (both backward entry points): dy is such a pair of planes [2][T,B,H] and
+ *             the shared output gradient is their sum (persistent kernels only).
+ * asr_lstm_fused_supported returns bit 0 for the forward, bit 1 for this entry point (the
+ * batch must fit one launch of 16- or 24-row tiles); ASR_EUNSUPPORTED otherwise. */
+int asr_lstm_bidir_bwd_fused_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
+                                  const void *wihT_bf16, const int32_t *lens,
+                                  int T, int B, int H, const void *gates_bf16,
+                                  const float *csave, void *dgates_bf16, float *dx,
+                                  void *workspace, int64_t workspace_bytes,
+                                  uint32_t *err_flag, void *stream);
 
 int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
                             const int32_t *lens, int T, int B, int H,

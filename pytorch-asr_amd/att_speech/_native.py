@@ -66,6 +66,8 @@ _SIGNATURES = {
     'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'asr_lstm_fused_supported': (_i, [_i, _i]),
+    'asr_lstm_bidir_bwd_fused_bf16': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
+                                           _vp, _i64, _vp, _vp]),
     'asr_lstm_bidir_fwd_fused_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'asr_bn_act_workspace_bytes': (_i64, [_i]),
     'asr_bn_act_fwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
@@ -308,9 +310,10 @@ def lstm_bidir_fwd(gx, whh_bf16, lens, want_y=True):
     return y, ybf, gates, csave
 
 
-def lstm_fused_supported(B, H):
-    """asr_lstm_fused_supported: can asr_lstm_bidir_fwd_fused_bf16 run this (batch, hidden)?"""
-    return bool(lib().asr_lstm_fused_supported(int(B), int(H)))
+def lstm_fused_supported(B, H, backward=False):
+    """asr_lstm_fused_supported: can asr_lstm_bidir_fwd_fused_bf16 (bit 0) /
+    asr_lstm_bidir_bwd_fused_bf16 (bit 1) run this (batch, hidden)?"""
+    return bool(lib().asr_lstm_fused_supported(int(B), int(H)) & (2 if backward else 1))
 
 
 def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True):
@@ -338,24 +341,55 @@ def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True):
     return y, ybf, gates, csave
 
 
-def lstm_bidir_bwd(dy, whhT_bf16, lens, gates, csave):
+def _dy_mode(dy, planes):
+    if planes:
+        if dy.dim() != 4 or dy.shape[0] != 2:
+            raise ValueError('dy planes must be [2,T,B,H]')
+        return 2, dy.shape[1], dy.shape[2]
+    return int(dy.dim() == 3), dy.shape[0], dy.shape[1]
+
+
+def lstm_bidir_bwd(dy, whhT_bf16, lens, gates, csave, planes=False):
     """asr_lstm_bidir_bwd_bf16 -> dgates [T,B,2,4H] bf16.  dy [T,B,2,H], or [T,B,H] when
-    the two directions share one gradient (their outputs are summed)."""
+    the two directions share one gradient (their outputs are summed), or with `planes`
+    [2,T,B,H]: that shared gradient as the sum of two planes (lstm_bidir_bwd_fused's dx)."""
     dy = _dev(dy, torch.float32, 'dy')
     whhT_bf16 = _dev(whhT_bf16, torch.bfloat16, 'whhT')
     lens = _dev(lens, torch.int32, 'lens')
-    shared = dy.dim() == 3
-    T, B = dy.shape[0], dy.shape[1]
+    mode, T, B = _dy_mode(dy, planes)
     H = dy.shape[-1]
     L = lib()
     dgates = torch.empty((T, B, 2, 4 * H), dtype=torch.bfloat16, device=dy.device)
     nbytes = L.asr_lstm_workspace_bytes(B, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
-    check(L.asr_lstm_bidir_bwd_bf16(_p(dy), int(shared), _p(whhT_bf16), _p(lens), T, B, H,
+    check(L.asr_lstm_bidir_bwd_bf16(_p(dy), mode, _p(whhT_bf16), _p(lens), T, B, H,
                                     _p(gates), _p(csave), _p(dgates), _p(ws), nbytes,
                                     _p(_lstm_err_flag(dy.device)), _stream()),
           'asr_lstm_bidir_bwd_bf16')
     return dgates
+
+
+def lstm_bidir_bwd_fused(dy, whhT_bf16, wihT_bf16, lens, gates, csave, planes=False):
+    """asr_lstm_bidir_bwd_fused_bf16 -> (dgates [T,B,2,4H] bf16, dx [2,T,B,H] f32 planes whose
+    sum is the layer's input gradient).  whhT, wihT: [2,H,4H] bf16; dy as in lstm_bidir_bwd."""
+    dy = _dev(dy, torch.float32, 'dy')
+    whhT_bf16 = _dev(whhT_bf16, torch.bfloat16, 'whhT')
+    wihT_bf16 = _dev(wihT_bf16, torch.bfloat16, 'wihT')
+    lens = _dev(lens, torch.int32, 'lens')
+    mode, T, B = _dy_mode(dy, planes)
+    H = dy.shape[-1]
+    if tuple(wihT_bf16.shape) != (2, H, 4 * H) or tuple(whhT_bf16.shape) != (2, H, 4 * H):
+        raise ValueError('lstm_bidir_bwd_fused: the layer input size must equal the hidden size')
+    L = lib()
+    dgates = torch.empty((T, B, 2, 4 * H), dtype=torch.bfloat16, device=dy.device)
+    dx = torch.empty((2, T, B, H), dtype=torch.float32, device=dy.device)
+    nbytes = L.asr_lstm_workspace_bytes(B, H)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    check(L.asr_lstm_bidir_bwd_fused_bf16(_p(dy), mode, _p(whhT_bf16), _p(wihT_bf16), _p(lens), T, B, H,
+                                          _p(gates), _p(csave), _p(dgates), _p(dx), _p(ws), nbytes,
+                                          _p(_lstm_err_flag(dy.device)), _stream()),
+          'asr_lstm_bidir_bwd_fused_bf16')
+    return dgates, dx
 
 
 class GroupedGraph(object):

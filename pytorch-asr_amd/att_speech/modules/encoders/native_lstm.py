@@ -146,16 +146,31 @@ class BiLSTMStackFunction(torch.autograd.Function):
     def backward(ctx, dy):
         lens_dev, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         grads = [None] * (4 * ctx.n)
-        dy = dy.contiguous()
+        dy, planes = dy.contiguous(), False
+        # opt-in: measured slower than recurrence + GEMM at the bench shape (csrc/lstm.hip,
+        # lstm_bwd_dx_kernel)
+        fuse_ok = os.environ.get('ASR_LSTM_FUSED_BWD', '0') == '1'
         for l in range(ctx.n - 1, -1, -1):
             xb, w_ih, whh, ybf, gates, csave = saved[6 * l:6 * l + 6]
             _, T2, B, H = ybf.shape
             T, F = T2 - 2, xb.shape[1]
-            dgb = _native.lstm_bidir_bwd(dy, whh.transpose(1, 2).contiguous(), lens_dev, gates, csave)
+            whhT = whh.transpose(1, 2).contiguous()
+            need_dx = l > 0 or ctx.needs_input_grad[0]
+            if need_dx and l > 0 and F == H and fuse_ok and _native.lstm_fused_supported(B, H, backward=True):
+                # the input gradient comes out of the recurrence (one plane per direction) and
+                # goes into the layer below as it is: no [T*B, 8H] x [8H, F] GEMM
+                dgb, dy_next = _native.lstm_bidir_bwd_fused(
+                    dy, whhT, w_ih.view(2, 4 * H, F).transpose(1, 2).contiguous(), lens_dev,
+                    gates, csave, planes=planes)
+                planes_next = True
+            else:
+                dgb = _native.lstm_bidir_bwd(dy, whhT, lens_dev, gates, csave, planes=planes)
+                dy_next, planes_next = None, False
+                if need_dx:
+                    dy_next = _mm_f32(dgb.view(T * B, 8 * H), w_ih.t().contiguous().t()).view(T, B, F)
             dw_ih, dw_hh = _weight_gradients(dgb, xb, ybf, T, B, H, F)
             grads[4 * l:4 * l + 4] = [dw_ih[:4 * H], dw_hh[0], dw_ih[4 * H:], dw_hh[1]]
-            if l > 0 or ctx.needs_input_grad[0]:
-                dy = _mm_f32(dgb.view(T * B, 8 * H), w_ih.t().contiguous().t()).view(T, B, F)
+            dy, planes = dy_next, planes_next
         return (dy if ctx.needs_input_grad[0] else None, None) + tuple(grads)
 
 

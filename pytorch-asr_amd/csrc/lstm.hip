@@ -300,7 +300,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdParams p) {
 
 struct LstmBwdParams {
     const float *dy;        // [T,B,2,H] gradient w.r.t. the per-direction outputs, or [T,B,H]
-    int dy_shared;          // != 0: one gradient for both directions (the directions are summed)
+    int dy_shared;          // 1: one gradient for both directions (the directions are summed);
+                            // 2: that gradient as the sum of two planes [2][T,B,H] (the `dx`
+                            //    planes of the layer above; persistent kernels only)
+    const __bf16 *wihT;     // fused input gradient (lstm_bwd_dx_kernel, F == H): fragment-major pack
+                            // of W_ihᵀ [2 dir][H rows (input feature)][4H cols]
+    float *dx;              // ... output [2 dir][T,B,H]: dgates_dir · W_ih_dir per direction
     const __bf16 *whhT;     // fragment-major pack of W_hhᵀ: [2 dir][H rows][4H cols]
     const int32_t *lens;
     int T, B, H;
@@ -469,10 +474,10 @@ __device__ __forceinline__ bool team_wait(unsigned *ctr, unsigned target, unsign
 typedef __attribute__((ext_vector_type(4))) int rsrc_words;
 __device__ __forceinline__ rsrc_words raw_rsrc(const void *base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
-    rsrc_words r;
-    r.x = (int)(unsigned)a;
-    r.y = (int)((unsigned)(a >> 32) & 0xffffu);
-    r.z = (int)bytes;
+    rsrc_words r;            // (readfirstlane: the descriptor must sit in SGPRs for the asm)
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
     r.w = 0x00020000;
     return r;
 }
@@ -484,8 +489,65 @@ __device__ __forceinline__ void dma16_s(rsrc_words r, unsigned lds_byte, unsigne
                  : "s"(lds_byte), "v"(voff), "s"(r), "s"(soff)
                  : "memory");
 }
+__device__ __forceinline__ void dma16_sc1(rsrc_words r, unsigned lds_byte, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen sc1 lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_byte), "v"(voff), "s"(r), "s"(soff)
+                 : "memory");
+}
+// four of them, 1 KiB apart on BOTH sides (the instruction offset moves the LDS and the
+// global address alike): one M0 set-up for four k-steps of a fragment-major tile
+__device__ __forceinline__ void dma16x4_sc1(rsrc_words r, unsigned lds_byte, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen sc1 lds\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen offset:1024 sc1 lds\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen offset:2048 sc1 lds\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen offset:3072 sc1 lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_byte), "v"(voff), "s"(r), "s"(soff)
+                 : "memory");
+}
+// 64 lanes x 4 bytes
+__device__ __forceinline__ void dma4_s(rsrc_words r, unsigned lds_byte, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_byte), "v"(voff), "s"(r), "s"(soff)
+                 : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void *ptr) {
     return (unsigned)(size_t)((__attribute__((address_space(3))) const void *)ptr);
+}
+
+// acc += A[32 x 16*(K1-K0)] · B over the k-steps K0..K1-1: the A fragments (1 KiB apart in
+// LDS, fragment-major) are read D k-steps ahead into a rotating register set.  Written as
+// one dependent ds_read -> MFMA pair per k-step the chain pays the LDS latency (~100
+// cycles) 20 times per phase: measured 1998 cycles for 20 MFMAs that need 640 in the pipe.
+template <int K0, int K1, int D, int KS>
+__device__ __forceinline__ f32x16 mfma_chain(const bf16x8 *al, const bf16x8 (&fb)[KS], f32x16 acc) {
+    bf16x8 a[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (K0 + d < K1) a[d] = al[(K0 + d) * 64];
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(k - K0) % D], fb[k], acc, 0, 0, 0);
+        if (k + D < K1) a[(k - K0) % D] = al[(k + D) * 64];
+    }
+    // keep that order: the scheduler otherwise sinks every read next to its MFMA again
+#pragma unroll
+    for (int d = 0; d < D; ++d) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (k + D < K1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    return acc;
 }
 
 struct LstmTeamCtl {
@@ -638,14 +700,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
                 for (int g = 0; g < 4; ++g) pgx[e][g] = ld_gx(vgx[e], (u32)t0 * fgx + (u32)g * H * GXE);
         }
     }
+    constexpr int AD = XF ? 2 : 4;       // A fragments in flight (registers are short with two weight slices)
     f32x16 accx;                 // XF: x_t · W_ih of this wave's (gate, column half)
     auto x_mfma = [&]() {
 #pragma unroll
         for (int i = 0; i < 16; ++i) accx[i] = 0.f;
         const bf16x8 *xl = reinterpret_cast<const bf16x8 *>(x_lds) + lane;
-#pragma unroll
-        for (int k = 0; k < KS; ++k)
-            accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[k * 64], fx[XF ? k : 0], accx, 0, 0, 0);
+        if constexpr (XF) accx = mfma_chain<0, KS, AD>(xl, fx, accx);
     };
     float sog[NE][4] = {}, soh[NE] = {}, sc[NE] = {};
     bool sact[NE] = {};
@@ -760,9 +821,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             }
             const bf16x8 *al = reinterpret_cast<const bf16x8 *>(a_lds) + lane;
-#pragma unroll
-            for (int k = 0; k < KS; ++k)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[k * 64], fb[k], acc, 0, 0, 0);
+            acc = mfma_chain<0, KS, AD>(al, fb, acc);
             const int c32 = lane & 31;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -888,37 +947,41 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
     // (as in the forward kernel; the host checks every tensor is < 4 GiB)
     typedef unsigned int u32;
     constexpr u32 OOBV = 0xFFFFFFFFu;
-    u32 vg[NE], vcs[NE], vdy[NE], vdg[NE];
+    u32 vcs[NE], vdy[NE], vdg[NE];        // gate records: 2 * vcs
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int b = b0 + e * 8 + wave;
-        vg[e] = (u32)((dir * B + bcl[e]) * H + j) * 8u;
         vcs[e] = (u32)((dir * B + bcl[e]) * H + j) * 4u;
         vdy[e] = (u32)(p.dy_shared ? bcl[e] * H + j : (bcl[e] * 2 + dir) * H + j) * 4u;
         vdg[e] = b < B ? (u32)((b * 2 + dir) * H4 + j) * 2u : OOBV;
     }
     const u32 fg = (u32)B * 2u * H * 8u, fcs = (u32)B * 2u * H * 4u;
     const u32 fdy = (u32)B * H * 4u * (p.dy_shared ? 1u : 2u), fdg = (u32)B * 2u * H4 * 2u;
+    // dy_shared == 2: the second plane lies T frames further on; otherwise that load is out
+    // of range and returns 0
+    const u32 dy2 = p.dy_shared == 2 ? (u32)T * fdy : 0x80000000u;
     const __amdgpu_buffer_rsrc_t gR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<u32x2 *>(p.gates), 0, (int)((u32)T * fg), 0x00020000);
     const __amdgpu_buffer_rsrc_t csR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.csave), 0, (int)((u32)T * fcs), 0x00020000);
     const __amdgpu_buffer_rsrc_t dyR = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.dy), 0, (int)((u32)T * fdy), 0x00020000);
+        const_cast<float *>(p.dy), 0,
+        __builtin_amdgcn_readfirstlane((int)((u32)T * fdy * (p.dy_shared == 2 ? 2u : 1u))), 0x00020000);
     const __amdgpu_buffer_rsrc_t dgR = __builtin_amdgcn_make_buffer_rsrc(
         p.dgates, 0, (int)((u32)T * fdg), 0x00020000);
     auto ldf = [&](__amdgpu_buffer_rsrc_t R, u32 voff, u32 soff) -> float {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R, voff, soff, 0));
     };
-    struct Pre { float g[NE][4], cp[NE], dy[NE]; };
+    struct Pre { u32x2 g[NE]; float cp[NE], dy[NE], dyb[NE]; };     // gates stay packed until used
     auto fetch = [&](int t, Pre &q) {
         const int tp = dir == 0 ? t - 1 : t + 1;
         const int tpc = tp < 0 ? 0 : (tp >= T ? T - 1 : tp);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            unpack_gates(__builtin_amdgcn_raw_buffer_load_b64(gR, vg[e], (u32)t * fg, 0), q.g[e]);
+            q.g[e] = __builtin_amdgcn_raw_buffer_load_b64(gR, vcs[e] * 2u, (u32)t * fg, 0);
             q.cp[e] = ldf(csR, vcs[e], (u32)tpc * fcs);
             q.dy[e] = ldf(dyR, vdy[e], (u32)t * fdy);
+            q.dyb[e] = ldf(dyR, vdy[e], (u32)t * fdy + dy2);
         }
     };
     Pre cur;
@@ -998,9 +1061,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             const bf16x8 *al = reinterpret_cast<const bf16x8 *>(a_lds) + (size_t)kq * KS * 64 + lane;
-#pragma unroll
-            for (int k = 0; k < KS; ++k)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[k * 64], fb[k], acc, 0, 0, 0);
+            acc = mfma_chain<0, KS, 4>(al, fb, acc);
             const int c32 = lane & 31;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -1018,11 +1079,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
             const int row = e * 8 + wave;
             float od[4];
             if (t < len[e]) {
-                const float dh = cur.dy[e] + (part[0][row][col] + part[1][row][col]) +
+                const float dh = (cur.dy[e] + cur.dyb[e]) + (part[0][row][col] + part[1][row][col]) +
                                  (part[2][row][col] + part[3][row][col]);
                 const float cp = (tp >= 0 && tp < len[e]) ? cur.cp[e] : 0.f;
-                float dcout;
-                lstm_cell_bwd(cur.g[e], pcs[e], cp, dh, dcarry[e], od, dcout);
+                float dcout, gt[4];
+                unpack_gates(cur.g[e], gt);
+                lstm_cell_bwd(gt, pcs[e], cp, dh, dcarry[e], od, dcout);
                 dcarry[e] = dcout;
                 if (dead) od[0] = od[1] = od[2] = od[3] = __builtin_nanf("");
             } else {
@@ -1057,6 +1119,342 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_kernel(LstmBwdParams p, 
         PSTAMP(5);
     }
     if (T > 0) bulk_store(true);          // the last step's
+#ifdef ASR_LSTM_STAMPS
+    __syncthreads();
+    if (tid == 0 && b0 < B)
+        for (int i = 0; i < 6; ++i)
+            p.dgates[(((size_t)0 * B + b0) * 2 + dir) * H4 + j0 + i] = (__bf16)((float)pst[i] / T / 16.f);
+#endif
+}
+
+// Backward recurrence WITH the input gradient: dx_t = dgates_t · W_ih per direction
+// (replaces the [T·B, 8H] x [8H, F] library GEMM behind asr_lstm_bidir_bwd_bf16 when F == H).
+// MEASURED SLOWER than recurrence + GEMM at the bench shape (B=576, H=320: 1669 us against
+// 1246 + 331): unlike the forward kernel, whose hand-off waits were idle, every phase of the
+// backward step is bound by what a wave has to ISSUE, so the dx product (+800 cycles per
+// step beyond the team wait it overlaps), the partial-sum read-out (+500) and the operand
+// DMAs (+700) all add to the step (ablation stamps).  Callers opt in
+// (att_speech: ASR_LSTM_FUSED_BWD=1); the parity tests run it either way.
+// Same team protocol, tiles and arithmetic as lstm_bwd_persist_kernel; what differs:
+//  * the team's dgates tile of step s stays in a_lds until the tile of step s+1 replaces it,
+//    so every wave multiplies it with its W_ihᵀ slice (registers, next to the W_hhᵀ slice) at
+//    the top of step s+2 — in the window in which the workgroup waits for the team counter
+//    anyway; the four K-quarter partials meet in `part` (free between the cell phase and the
+//    next dh product) and leave as one coalesced fp32 row per wave.  The two directions write
+//    separate planes; the layer below reads both (dy_shared == 2);
+//  * two weight slices take 160 of the 256 VGPRs, so nothing else may be staged in registers:
+//    the hand-off tile comes global -> LDS by LDS-DMA (the buffer is fragment-major, 1 KiB
+//    per k-step, lane-linear on both sides), and so do the pointwise operands of the next
+//    step (saved gates, neighbour cell state, dy): issued behind the team signal, landed
+//    under the dx product, read from LDS in the cell phase;
+//  * every per-row quantity (lengths, row offsets) is wave-uniform and lives in SGPRs.
+template <int KS, int NE>
+__global__ __launch_bounds__(512) void lstm_bwd_dx_kernel(LstmBwdParams p, LstmTeamCtl ctl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KS4 = 4 * KS, RL = 8 * NE;
+    __bf16 *a_lds = reinterpret_cast<__bf16 *>(smem);                       // 4*KS KiB
+    float (*part)[32][65] = reinterpret_cast<float (*)[32][65]>(smem + KS4 * 1024);
+    __bf16 *dg_lds = reinterpret_cast<__bf16 *>(smem + KS4 * 1024 + ASR_GLDS_BYTES);   // 16 KiB
+    unsigned char *pre = smem + KS4 * 1024 + ASR_GLDS_BYTES + 16384;
+    u32x2 (*pg)[64] = reinterpret_cast<u32x2 (*)[64]>(pre);                 // [RL][64] gate records
+    float (*pcp)[64] = reinterpret_cast<float (*)[64]>(pre + RL * 512);     // [RL][64] neighbour c
+    float (*pdy)[64] = reinterpret_cast<float (*)[64]>(pre + RL * 768);     // [2][RL][64] dy planes
+    __shared__ int dead_s;
+    typedef unsigned int u32;
+    constexpr u32 OOBV = 0x80000000u;
+    const int H = p.H, B = p.B, T = p.T, H4 = 4 * p.H;
+    int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
+    if (ctl.xcd_teams) {                     // XCD-affine 1-D grid, as in lstm_bwd_persist_kernel
+        const int slot = blockIdx.x >> 3, team = (slot / (p.H / 64)) * 8 + (blockIdx.x & 7);
+        if (team >= ctl.xcd_teams) return;
+        jt = slot % (p.H / 64);
+        btile = (team >> 1) + ctl.bt0;
+        dir = team & 1;
+    }
+    const int j0 = jt * 64, b0 = btile * RL, njt = H / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = wave >> 1, js = wave & 1;
+    const size_t Bp = ctl.rows;
+    unsigned *myctr = ctl.ctr + ((size_t)dir * ctl.nbt + btile) * 32;
+    if (tid == 0) dead_s = 0;
+    for (int i = tid; i < 8192; i += 512) dg_lds[i] = (__bf16)0.f;      // padding rows stay 0
+    for (int i = tid; i < KS4 * 64; i += 512)
+        reinterpret_cast<u32x4 *>(a_lds)[i] = u32x4{0u, 0u, 0u, 0u};
+
+    bf16x8 fb[KS], fxb[KS];
+    {
+        const size_t wo = (size_t)dir * H * H4 +
+                          (((size_t)(2 * jt + js) * KS4 + (size_t)kq * KS) * 64 + lane) * 8;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) fb[k] = *reinterpret_cast<const bf16x8 *>(p.whhT + wo + k * 512);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) fxb[k] = *reinterpret_cast<const bf16x8 *>(p.wihT + wo + k * 512);
+    }
+    const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(
+        p.dgbuf, 0, (int)(2 * 2 * Bp * H4 * 2), 0x00020000);
+    const rsrc_words dresD = raw_rsrc(p.dgbuf, (unsigned)(2 * 2 * Bp * H4 * 2));
+
+    // rows of this wave: b = b0 + e*8 + wave (wave-uniform: SGPRs)
+    const int col = lane;
+    int len[NE], bc[NE];
+    bool inb[NE];
+    float dcarry[NE], pcs[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int b = b0 + e * 8 + wave;
+        inb[e] = b < B;
+        bc[e] = b < B ? b : B - 1;
+        len[e] = __builtin_amdgcn_readfirstlane(b < B ? p.lens[bc[e]] : 0);
+        dcarry[e] = 0.f;
+    }
+    const u32 l4 = (u32)lane * 4u, l2 = (u32)lane * 2u;
+    const u32 fg = (u32)B * 2u * H * 8u, fcs = (u32)B * 2u * H * 4u;
+    const u32 fdy = (u32)B * H * 4u * (p.dy_shared ? 1u : 2u), fdg = (u32)B * 2u * H4 * 2u;
+    const u32 fdx = (u32)B * H * 4u;
+    const rsrc_words gD = raw_rsrc(p.gates, (u32)T * fg);
+    const rsrc_words csD = raw_rsrc(p.csave, (u32)T * fcs);
+    const rsrc_words dyD = raw_rsrc(p.dy, (u32)T * fdy * (p.dy_shared == 2 ? 2u : 1u));
+    const __amdgpu_buffer_rsrc_t dgR = __builtin_amdgcn_make_buffer_rsrc(
+        p.dgates, 0, (int)((u32)T * fdg), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dxR = __builtin_amdgcn_make_buffer_rsrc(
+        p.dx, 0, (int)(2u * (u32)T * fdx), 0x00020000);
+
+    // pointwise operands of frame t (all RL rows of the tile) -> LDS: 5*RL/4 LDS-DMAs of
+    // 1 KiB (two rows of gate records, or four rows of c / dy), dealt round-robin to the
+    // waves; the per-lane source offsets are loop-invariant
+    constexpr int NQ = 5 * RL / 4, NQW = (NQ + 7) / 8;
+    u32 pvo[NQW];
+#pragma unroll
+    for (int i = 0; i < NQW; ++i) {
+        const int q = wave + 8 * i;
+        if (q < RL / 2) {
+            const int r = 2 * q + (lane >> 5), b = b0 + r < B ? b0 + r : B - 1;
+            pvo[i] = (u32)((dir * B + b) * H + j0) * 8u + (u32)(lane & 31) * 16u;
+        } else {
+            const int qq = q < 3 * RL / 4 ? q - RL / 2 : (q < RL ? q - 3 * RL / 4 : q - RL);
+            const int r = 4 * qq + (lane >> 4), b = b0 + r < B ? b0 + r : B - 1;
+            if (q < 3 * RL / 4) pvo[i] = (u32)((dir * B + b) * H + j0) * 4u + (u32)(lane & 15) * 16u;
+            else pvo[i] = (u32)(p.dy_shared ? b * H + j0 : (b * 2 + dir) * H + j0) * 4u + (u32)(lane & 15) * 16u;
+            if (q >= RL && p.dy_shared != 2) pvo[i] = OOBV;      // no second dy plane: zeros
+        }
+    }
+    auto pre_dma = [&](int t) {
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        const int tpc = tp < 0 ? 0 : (tp >= T ? T - 1 : tp);
+#pragma unroll
+        for (int i = 0; i < NQW; ++i) {
+            const int q = wave + 8 * i;
+            if (q < RL / 2) dma16_s(gD, lds_addr(pre) + (unsigned)q * 1024u, pvo[i], (u32)t * fg);
+            else if (q < 3 * RL / 4) dma16_s(csD, lds_addr(pre) + (unsigned)q * 1024u, pvo[i], (u32)tpc * fcs);
+            else if (q < RL) dma16_s(dyD, lds_addr(pre) + (unsigned)q * 1024u, pvo[i], (u32)t * fdy);
+            else if (q < NQ) dma16_s(dyD, lds_addr(pre) + (unsigned)q * 1024u, pvo[i], (u32)(T + t) * fdy);
+        }
+    };
+    __bf16 sod[NE][4] = {};
+    int st = 0;
+    auto bulk_store = [&](bool live) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_raw_buffer_store_b16(
+                    (short)__builtin_bit_cast(unsigned short, sod[e][g]), dgR,
+                    live && inb[e] ? l2 : OOBV,
+                    (u32)st * fdg + (u32)(((b0 + e * 8 + wave) * 2 + dir) * H4 + g * H + j0) * 2u, 0);
+    };
+    // a_lds (the dgates of one step, all 4H columns) x this wave's W_ihᵀ slice -> part
+    auto dx_mfma = [&]() {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const bf16x8 *al = reinterpret_cast<const bf16x8 *>(a_lds) + (size_t)kq * KS * 64 + lane;
+        acc = mfma_chain<0, KS, 2>(al, fxb, acc);
+        const int c32 = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            part[kq][row][js * 32 + c32] = acc[i];
+        }
+    };
+    // the four K-quarter partials in `part` -> dx[dir][frame of step sq]
+    auto dx_store = [&](bool live, int sq) {
+        const int tq = live ? (dir == 0 ? T - 1 - sq : sq) : 0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int row = e * 8 + wave;
+            const float v = (part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]);
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __builtin_bit_cast(int, v), dxR, live && inb[e] ? l4 : OOBV,
+                (u32)(dir * T + tq) * fdx + (u32)((b0 + e * 8 + wave) * H + j0) * 4u, 0);
+        }
+    };
+    // the other workgroups' 4*(KS-4) k-steps of the team's dgates tile, (KS-4)/2 per wave
+    auto tile_dma = [&](int step) {
+        const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H4 +
+                                          (size_t)btile * KS4 * 512) * 2);
+        const u32 voff = (lane & 31) < RL ? (u32)lane * 16u : OOBV;
+        if constexpr (KS > 4) {
+            // a wave's k-steps come in runs of four consecutive ones when (KS-4)/2 % 4 == 0
+            // (the gap left by this workgroup's own k-steps starts at a multiple of four)
+            constexpr int PW = (KS - 4) / 2, GR = PW % 4 == 0 ? 4 : 1;
+#pragma unroll
+            for (int i = 0; i < PW; i += GR) {
+                const int ko = wave * PW + i, g = ko / (KS - 4), r = ko - g * (KS - 4);
+                const int k = g * KS + (r < 4 * jt ? r : r + 4);
+                if constexpr (GR == 4)
+                    dma16x4_sc1(dresD, lds_addr(a_lds) + (unsigned)k * 1024u, voff, base + (unsigned)k * 1024u);
+                else
+                    dma16_sc1(dresD, lds_addr(a_lds) + (unsigned)k * 1024u, voff, base + (unsigned)k * 1024u);
+            }
+        }
+    };
+    auto own_copy = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * 512 + tid, bi = c >> 6;         // bi = gate * 4 + kk
+            reinterpret_cast<u32x4 *>(a_lds)[((bi >> 2) * KS + 4 * jt + (bi & 3)) * 64 + (c & 63)] =
+                reinterpret_cast<const u32x4 *>(dg_lds)[c];
+        }
+    };
+    {
+        const int t0 = dir == 0 ? T - 1 : 0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            pcs[e] = p.csave[(((size_t)t0 * 2 + dir) * B + bc[e]) * H + j0 + col];
+    }
+    const bool last_q = wave + 8 * (NQW - 1) < NQ;      // does this wave issue NQW operand DMAs, or one less
+    // everything loaded so far lands before the loop: the compiler cannot count the LDS-DMA
+    // inside the asm (see lstm_fwd_persist_kernel)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        asm volatile("" : "+v"(fb[k]));
+        asm volatile("" : "+v"(fxb[k]));
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) asm volatile("" : "+v"(pcs[e]));
+
+    PSTAMP_DECL;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir == 0 ? T - 1 - step : step;
+        // The team counter is looked at before and in the middle of the dx product (a_lds still
+        // holds the dgates of step - 2, loaded for the dh product of step - 1): the round trip
+        // of the poll runs under the MFMAs instead of after them
+        const unsigned target = (unsigned)(njt * step);
+        const bool poller = step > 0 && tid == 0 && !dead_s;
+        unsigned seen = 0;
+        if (poller) seen = __hip_atomic_load(myctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (step >= 2) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const bf16x8 *al = reinterpret_cast<const bf16x8 *>(a_lds) + (size_t)kq * KS * 64 + lane;
+            acc = mfma_chain<0, KS / 2, 2>(al, fxb, acc);
+            if (poller && seen < target)
+                seen = __hip_atomic_load(myctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc = mfma_chain<KS / 2, KS, 2>(al, fxb, acc);
+            const int c32 = lane & 31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                part[kq][row][js * 32 + c32] = acc[i];
+            }
+        }
+        if (poller && seen < target) {
+            if (!team_wait(myctr, target, ctl.spin_limit, ctl.err)) dead_s = 1;
+        }
+        PSTAMP(0);
+        __syncthreads();
+        tile_dma(step);
+        bulk_store(step > 0);     // previous step's dgates rows, under the tile's flight
+        own_copy();
+        dx_store(step >= 2, step - 2);
+        pre_dma(t);               // this step's pointwise operands: needed two barriers further on
+        // the tile has landed once all but the stores and operand DMAs behind it are done
+        // (VMEM retires in issue order)
+        if (last_q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NE + NQW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NE + NQW - 1) : "memory");
+        __syncthreads();
+        PSTAMP(1);
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const bf16x8 *al = reinterpret_cast<const bf16x8 *>(a_lds) + (size_t)kq * KS * 64 + lane;
+            acc = mfma_chain<0, KS, 2>(al, fb, acc);
+            const int c32 = lane & 31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                part[kq][row][js * 32 + c32] = acc[i];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the operand DMAs
+        __syncthreads();
+        PSTAMP(2);
+        const bool dead = dead_s != 0;
+        st = t;
+        const int tp = dir == 0 ? t - 1 : t + 1;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int row = e * 8 + wave;
+            float od[4];
+            const float cpn = pcp[row][col];
+            if (t < len[e]) {
+                const float dh = (pdy[row][col] + pdy[RL + row][col]) +
+                                 (part[0][row][col] + part[1][row][col]) +
+                                 (part[2][row][col] + part[3][row][col]);
+                const float cp = (tp >= 0 && tp < len[e]) ? cpn : 0.f;
+                float dcout, gt[4];
+                unpack_gates(pg[row][col], gt);
+                lstm_cell_bwd(gt, pcs[e], cp, dh, dcarry[e], od, dcout);
+                dcarry[e] = dcout;
+                if (dead) od[0] = od[1] = od[2] = od[3] = __builtin_nanf("");
+            } else {
+                od[0] = od[1] = od[2] = od[3] = 0.f;
+                dcarry[e] = 0.f;
+            }
+            const int slot = ((col >> 4) * 64 + row + 32 * ((col >> 3) & 1)) * 8 + (col & 7);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                sod[e][g] = (__bf16)od[g];
+                dg_lds[g * 2048 + slot] = sod[e][g];
+            }
+            pcs[e] = cpn;               // c of the frame the next step visits
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int bi = wave * 2 + r, g = bi >> 2, kk = bi & 3;
+            const u32x4 v = reinterpret_cast<const u32x4 *>(dg_lds)[bi * 64 + lane];
+            const unsigned off = (unsigned)(((((size_t)((step + 1) & 1) * 2 + dir) * Bp * H4) +
+                                             ((size_t)btile * KS4 + g * KS + 4 * jt + kk) * 512 + lane * 8) * 2);
+            __builtin_amdgcn_raw_buffer_store_b128(v, dres, (lane & 31) < RL ? off : 0xFFFFFFFFu,
+                                                   0, ASR_SC1);
+        }
+        PSTAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        PSTAMP(4);
+        if (tid == 0) __hip_atomic_fetch_add(myctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PSTAMP(5);
+    }
+    bulk_store(true);                     // the last step's dgates rows
+    // dx of the last two steps: step T-2's tile is in a_lds, step T-1's comes with one more
+    // hand-off round
+    if (T >= 2) dx_mfma();
+    if (tid == 0 && !dead_s) {
+        if (!team_wait(myctr, (unsigned)(njt * T), ctl.spin_limit, ctl.err)) dead_s = 1;
+    }
+    __syncthreads();
+    tile_dma(T);
+    own_copy();
+    dx_store(T >= 2, T - 2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NE) : "memory");
+    __syncthreads();
+    dx_mfma();
+    __syncthreads();
+    dx_store(true, T - 1);
 #ifdef ASR_LSTM_STAMPS
     __syncthreads();
     if (tid == 0 && b0 < B)
@@ -1104,6 +1502,12 @@ inline int64_t plane_rows(int B) {
     return a > b ? a : b;
 }
 
+inline int pick_tile_rows(int B, int njt, int cus) {
+    for (int cand = 2; cand <= 4; ++cand)
+        if (2 * njt * ((B + 8 * cand - 1) / (8 * cand)) <= cus) return cand;
+    return 4;
+}
+
 template <typename P>
 bool launch_persist(void (*const kerns[3])(P, LstmTeamCtl), const P &p, int B, int H,
                     size_t lds_need, unsigned *ctl_words, unsigned *err_flag, hipStream_t s) {
@@ -1113,9 +1517,7 @@ bool launch_persist(void (*const kerns[3])(P, LstmTeamCtl), const P &p, int B, i
     // batch-tile rows: the smallest of 16 / 24 / 32 whose whole grid is one launch with one
     // workgroup per CU (more workgroups = less work on each one's critical path); 32-row
     // tiles in several launches when the batch is too large for that
-    int ne = 4;
-    for (int cand = 2; cand <= 4; ++cand)
-        if (2 * njt * ((B + 8 * cand - 1) / (8 * cand)) <= cus) { ne = cand; break; }
+    const int ne = pick_tile_rows(B, njt, cus);
     void (*kern)(P, LstmTeamCtl) = kerns[ne - 2];
     if (!kern) return false;
     const int nbt = (B + 8 * ne - 1) / (8 * ne);
@@ -1194,7 +1596,11 @@ extern "C" int asr_lstm_bidir_fwd_fused_bf16(const void *x_bf16, const void *wih
 extern "C" int asr_lstm_fused_supported(int B, int H) {
     if (!persist_enabled() || B <= 0) return 0;
     if (H != 64 && H != 128 && H != 256 && H != 320) return 0;
-    return cu_count() >= 2 * (H / 64) ? 1 : 0;
+    const int cus = cu_count(), njt = H / 64;
+    if (cus < 2 * njt) return 0;
+    // bit 0: forward (input projection); bit 1: backward (input gradient) — its kernel has no
+    // LDS left for 32-row batch tiles, i.e. the batch must fit one launch of 16/24-row tiles
+    return 1 | (pick_tile_rows(B, njt, cus) < 4 ? 2 : 0);
 }
 
 namespace {
@@ -1207,7 +1613,7 @@ int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *w
     if (T == 0) return ASR_OK;
     if (!whh_bf16 || !lens || !y_bf16 || !gates_bf16 || !csave || !workspace)
         return ASR_EINVAL;
-    if (fused && (!asr_lstm_fused_supported(B, H) || (uint64_t)T * B * H * 2 >= (1ull << 31)))
+    if (fused && (!(asr_lstm_fused_supported(B, H) & 1) || (uint64_t)T * B * H * 2 >= (1ull << 31)))
         return ASR_EUNSUPPORTED;
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -1275,16 +1681,45 @@ int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *w
 }
 }  // namespace
 
+namespace {
+int lstm_bwd_impl(const float *dy, int dy_shared, const void *whhT_bf16, const void *wihT_bf16,
+                  const int32_t *lens, int T, int B, int H, const void *gates_bf16,
+                  const float *csave, void *dgates_bf16, float *dx, void *workspace,
+                  int64_t workspace_bytes, uint32_t *err_flag, void *stream);
+}
+
 extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
                                        const int32_t *lens, int T, int B, int H,
                                        const void *gates_bf16, const float *csave,
                                        void *dgates_bf16,
                                        void *workspace, int64_t workspace_bytes,
                                        uint32_t *err_flag, void *stream) {
-    if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0) return ASR_EINVAL;
+    return lstm_bwd_impl(dy, dy_shared, whhT_bf16, nullptr, lens, T, B, H, gates_bf16, csave,
+                         dgates_bf16, nullptr, workspace, workspace_bytes, err_flag, stream);
+}
+
+extern "C" int asr_lstm_bidir_bwd_fused_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
+                                             const void *wihT_bf16, const int32_t *lens,
+                                             int T, int B, int H, const void *gates_bf16,
+                                             const float *csave, void *dgates_bf16, float *dx,
+                                             void *workspace, int64_t workspace_bytes,
+                                             uint32_t *err_flag, void *stream) {
+    if (!wihT_bf16 || !dx) return ASR_EINVAL;
+    return lstm_bwd_impl(dy, dy_shared, whhT_bf16, wihT_bf16, lens, T, B, H, gates_bf16, csave,
+                         dgates_bf16, dx, workspace, workspace_bytes, err_flag, stream);
+}
+
+namespace {
+int lstm_bwd_impl(const float *dy, int dy_shared, const void *whhT_bf16, const void *wihT_bf16,
+                  const int32_t *lens, int T, int B, int H, const void *gates_bf16,
+                  const float *csave, void *dgates_bf16, float *dx, void *workspace,
+                  int64_t workspace_bytes, uint32_t *err_flag, void *stream) {
+    const bool fused = wihT_bf16 != nullptr;
+    if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0 || dy_shared < 0 || dy_shared > 2) return ASR_EINVAL;
     if (T == 0) return ASR_OK;
     if (!dy || !whhT_bf16 || !lens || !gates_bf16 || !csave || !dgates_bf16 || !workspace)
         return ASR_EINVAL;
+    if (fused && !(asr_lstm_fused_supported(B, H) & 2)) return ASR_EUNSUPPORTED;
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmBwdParams p;
@@ -1292,6 +1727,7 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const voi
     const size_t dbytes = (size_t)2 * 2 * Bp * 4 * H * 2, cbytes = (size_t)2 * B * H * 4;
     __bf16 *wpack = (__bf16 *)((char *)workspace + dbytes + cbytes);
     p.dy = dy; p.dy_shared = dy_shared; p.whhT = wpack; p.lens = lens;
+    p.wihT = wpack + (size_t)2 * H * 4 * H; p.dx = dx;
     p.T = T; p.B = B; p.H = H;
     p.gates = (const u32x2 *)gates_bf16; p.csave = csave;
     p.dgbuf = (__bf16 *)workspace;
@@ -1301,19 +1737,28 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const voi
     // whhT_bf16 is [2][H][4H] row-major: rows = hidden unit j, cols = k over 4H
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
                        (const __bf16 *)whhT_bf16, wpack, 2, H, 4 * H, 0);
+    if (fused)          // wihT_bf16 is [2][H (input feature)][4H] row-major
+        hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
+                           (const __bf16 *)wihT_bf16, wpack + (size_t)2 * H * 4 * H, 2, H, 4 * H, 0);
     if (persist_enabled()) {
         unsigned *ctl_words = (unsigned *)((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B));
         zero_async(ctl_words, (size_t)ctl_bytes(B), s);
         void (*pk[3])(LstmBwdParams, LstmTeamCtl) = {nullptr, nullptr, nullptr};
-#define ASR_PICK(KSV) if (H == 16 * KSV) { pk[0] = lstm_bwd_persist_kernel<KSV, 2>; \
+#define ASR_PICK(KSV) if (H == 16 * KSV && !fused) { pk[0] = lstm_bwd_persist_kernel<KSV, 2>; \
         pk[1] = lstm_bwd_persist_kernel<KSV, 3>; pk[2] = lstm_bwd_persist_kernel<KSV, 4>; }
         ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24)
 #undef ASR_PICK
-        const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (1ull << 32);   // 32-bit byte offsets
-        if (fits32 && pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 4) * 1024 + ASR_GLDS_BYTES + 16384,
-                                 ctl_words, err_flag, s))
+#define ASR_PICK(KSV) if (H == 16 * KSV && fused) { pk[0] = lstm_bwd_dx_kernel<KSV, 2>; \
+        pk[1] = lstm_bwd_dx_kernel<KSV, 3>; }
+        ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16)
+#undef ASR_PICK
+        const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (1ull << 31);   // 32-bit byte offsets
+        const size_t lds = (size_t)(H / 4) * 1024 + ASR_GLDS_BYTES + 16384 + (fused ? 24 * 1280 : 0);
+        if (fits32 && (pk[2] || fused) && launch_persist(pk, p, B, H, lds, ctl_words, err_flag, s))
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
+    // the per-step kernels know neither the fused input gradient nor the two-plane dy
+    if (fused || dy_shared == 2) return ASR_EUNSUPPORTED;
     const int bt = 1;
     const dim3 grid(H / 32, (B + 32 * bt - 1) / (32 * bt), 2);
     void (*kern)(LstmBwdParams) = nullptr;
@@ -1328,3 +1773,4 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const voi
     }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
+}  // namespace

@@ -181,6 +181,53 @@ def test_fused_input_projection_matches_gemm_plus_recurrence(T, B, H, reps):
     assert out[0] is None and torch.equal(out[1], first[1])
 
 
+@pytest.mark.parametrize('T,B,H,reps', [
+    (1, 1, 64, 1),
+    (2, 3, 64, 1),
+    (23, 7, 64, 1),
+    (61, 45, 128, 1),
+    (19, 70, 256, 1),
+    (150, 96, 320, 1),
+    (334, 512, 320, 3),        # bench shape, repeated
+])
+def test_fused_input_gradient_matches_recurrence_plus_gemm(T, B, H, reps):
+    """asr_lstm_bidir_bwd_fused_bf16 (dx = dgates·W_ih inside the persistent backward kernel,
+    hand-off tile and pointwise operands by LDS-DMA) against asr_lstm_bidir_bwd_bf16 + the
+    GEMM: the gate gradients go through the same arithmetic in the same order, so they must
+    agree bit for bit (a stale tile, a late operand or a torn hand-off changes bits); the
+    sum of the two dx planes is the fp32 product of the same bf16 operands up to summation
+    order.  Also: a gradient handed in as two planes equals the same gradient pre-summed."""
+    from att_speech import _native
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(T * 13 + B)
+    lens = torch.randint(1, T + 1, (B,), generator=g).sort(descending=True)[0]
+    lens[0] = T
+    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 1.5).to(dev)
+    whh = (torch.randn(2, 4 * H, H, generator=g) * (1.0 / H ** 0.5)).to(dev, torch.bfloat16)
+    wih = (torch.randn(2, 4 * H, H, generator=g) * (1.0 / H ** 0.5)).to(dev, torch.bfloat16)
+    dya = torch.randn(T, B, H, generator=g).to(dev)
+    dyb = torch.randn(T, B, H, generator=g).to(dev)
+    lens_d = lens.to(dev, torch.int32)
+    assert _native.lstm_fused_supported(B, H, backward=True)
+    _, _, gates, csave = _native.lstm_bidir_fwd(gx, whh, lens_d)
+    whhT, wihT = whh.transpose(1, 2).contiguous(), wih.transpose(1, 2).contiguous()
+    dy = dya + dyb
+    want = _native.lstm_bidir_bwd(dy, whhT, lens_d, gates, csave)
+    want_dx = torch.mm(want.view(T * B, 8 * H), wih.view(8 * H, H), out_dtype=torch.float32).view(T, B, H)
+    for _ in range(reps):
+        for planes in (False, True):
+            arg = torch.stack([dya, dyb]) if planes else dy
+            dg, dx = _native.lstm_bidir_bwd_fused(arg, whhT, wihT, lens_d, gates, csave, planes=planes)
+            torch.cuda.synchronize()
+            _native.lstm_check_errors()
+            assert torch.equal(dg, want), float((dg.float() - want.float()).abs().max())
+            got = dx[0] + dx[1]
+            assert float((got - want_dx).abs().max()) <= 2e-3 * (1.0 + float(want_dx.abs().max()))
+    # the unfused kernel takes planes too (the layer below a fused one)
+    dg = _native.lstm_bidir_bwd(torch.stack([dya, dyb]), whhT, lens_d, gates, csave, planes=True)
+    assert torch.equal(dg, want)
+
+
 def test_handoff_timeout_surfaces_as_an_error(monkeypatch):
     """A persistent-recurrence hand-off whose spin bound expires poisons the outputs with
     NaN and sets the caller's error word; `_native.lstm_check_errors` (called once per step
@@ -208,11 +255,14 @@ def test_handoff_timeout_surfaces_as_an_error(monkeypatch):
     assert bool(torch.isfinite(y).all())
 
 
-def test_layer_stack_matches_chained_layers():
+@pytest.mark.parametrize('fused_bwd', [False, True])
+def test_layer_stack_matches_chained_layers(fused_bwd, monkeypatch):
     """native_lstm.bilstm_stack (one autograd node, bf16 planes between layers, no fp32 outputs
     of the inner layers) against the same layers applied one by one with summed directions:
     outputs and all gradients agree at the level of the bf16 inter-layer operand."""
     from att_speech.modules.encoders.native_lstm import bilstm, bilstm_stack
+    if fused_bwd:       # the opt-in input-gradient fusion (dx planes handed from layer to layer)
+        monkeypatch.setenv('ASR_LSTM_FUSED_BWD', '1')
     torch.manual_seed(5)
     dev = torch.device('cuda:0')
     T, B, F, H = 23, 37, 96, 128

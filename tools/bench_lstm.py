@@ -49,4 +49,12 @@ print('gemm + recurrence      %8.1f us' % timed(gemm_path))
 if _native.lstm_fused_supported(B, H):
     print('fused                  %8.1f us' % timed(fused_path))
 print('backward recurrence    %8.1f us' % timed(lambda: _native.lstm_bidir_bwd(dy, whhT, lens, out[2], out[3])))
+dgb = _native.lstm_bidir_bwd(dy, whhT, lens, out[2], out[3])
+wk = wih.t().contiguous().t()
+print('dx gemm only           %8.1f us' % timed(lambda: torch.mm(dgb.view(T * B, 8 * H), wk, out_dtype=torch.float32)))
+if _native.lstm_fused_supported(B, H, backward=True):
+    wihT = wih.view(2, 4 * H, H).transpose(1, 2).contiguous()
+    print('backward fused         %8.1f us' % timed(lambda: _native.lstm_bidir_bwd_fused(dy, whhT, wihT, lens, out[2], out[3])))
+    dxp = _native.lstm_bidir_bwd_fused(dy, whhT, wihT, lens, out[2], out[3])[1]
+    print('backward, dy as planes %8.1f us' % timed(lambda: _native.lstm_bidir_bwd(dxp, whhT, lens, out[2], out[3], planes=True)))
 _native.lstm_check_errors()
