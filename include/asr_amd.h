@@ -237,6 +237,22 @@ int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *whh_bf16,
                             void *workspace, int64_t workspace_bytes,
                             uint32_t *err_flag, void *stream);
 
+/* Weight gradients of one layer from the gate gradients, in one pass over them (replaces the
+ * three chunked library products + sums of the reference's autograd for nn.LSTM weights,
+ * encoder_utils.py:78,100):
+ *   dgates_bf16 [T*B, 2, 4H]  as written by asr_lstm_bidir_bwd_bf16
+ *   x_bf16      [T*B, H] layer input (input size == H), or NULL: then dw_ih must be NULL too
+ *               and only dw_hh is computed (first layer: the caller multiplies for dw_ih)
+ *   y_bf16      [2, T+2, B, H] the forward call's zero-padded bf16 outputs (h_{t-1} operands)
+ *   dw_ih [2*4H, H], dw_hh [2][4H][H]  f32 out (overwritten)
+ * Built for H = 320 (asr_lstm_wgrad_supported; ASR_EUNSUPPORTED otherwise).  fp32
+ * accumulation over all frames in a fixed order: deterministic. */
+int asr_lstm_wgrad_supported(int H);
+int64_t asr_lstm_wgrad_workspace_bytes(int T, int B, int H, int with_input);
+int asr_lstm_wgrad_bf16(const void *dgates_bf16, const void *x_bf16, const void *y_bf16,
+                        int T, int B, int H, float *dw_ih, float *dw_hh,
+                        void *workspace, int64_t workspace_bytes, void *stream);
+
 /* The same layer with the input projection fused into the persistent recurrence
  * (replaces the `x·W_ihᵀ` GEMM in front of asr_lstm_bidir_fwd_bf16 when the layer's input
  * size equals H, i.e. every BatchRNN after the first, encoder_utils.py:97-124):

@@ -66,6 +66,9 @@ _SIGNATURES = {
     'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'asr_lstm_fused_supported': (_i, [_i, _i]),
+    'asr_lstm_wgrad_supported': (_i, [_i]),
+    'asr_lstm_wgrad_workspace_bytes': (_i64, [_i, _i, _i, _i]),
+    'asr_lstm_wgrad_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_bidir_bwd_fused_bf16': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
                                            _vp, _i64, _vp, _vp]),
     'asr_lstm_bidir_fwd_fused_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -339,6 +342,33 @@ def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True):
                                           _p(_lstm_err_flag(dev)), _stream()),
           'asr_lstm_bidir_fwd_fused_bf16')
     return y, ybf, gates, csave
+
+
+def lstm_wgrad_supported(H):
+    return bool(lib().asr_lstm_wgrad_supported(int(H)))
+
+
+def lstm_wgrad(dgates, x_bf16, y_bf16):
+    """asr_lstm_wgrad_bf16: dgates [T,B,2,4H] bf16, x [T*B,H] bf16 or None, y_bf16 [2,T+2,B,H]
+    -> (dw_ih [8H,H] f32 or None, dw_hh [2,4H,H] f32)."""
+    dgates = _dev(dgates, torch.bfloat16, 'dgates')
+    y_bf16 = _dev(y_bf16, torch.bfloat16, 'y_bf16')
+    T, B, H = dgates.shape[0], dgates.shape[1], dgates.shape[3] // 4
+    dev = dgates.device
+    if x_bf16 is not None:
+        x_bf16 = _dev(x_bf16, torch.bfloat16, 'x')
+        if x_bf16.numel() != T * B * H:
+            raise ValueError('lstm_wgrad: x must be [T*B, H]')
+    L = lib()
+    dw_ih = torch.empty((8 * H, H), dtype=torch.float32, device=dev) if x_bf16 is not None else None
+    dw_hh = torch.empty((2, 4 * H, H), dtype=torch.float32, device=dev)
+    nbytes = L.asr_lstm_wgrad_workspace_bytes(T, B, H, int(x_bf16 is not None))
+    if nbytes < 0:
+        raise NativeLibraryError('asr_lstm_wgrad: unsupported hidden size %d' % H)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(L.asr_lstm_wgrad_bf16(_p(dgates), _p(x_bf16), _p(y_bf16), T, B, H, _p(dw_ih), _p(dw_hh),
+                                _p(ws), nbytes, _stream()), 'asr_lstm_wgrad_bf16')
+    return dw_ih, dw_hh
 
 
 def _dy_mode(dy, planes):

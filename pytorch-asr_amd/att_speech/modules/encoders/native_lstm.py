@@ -85,23 +85,34 @@ class BiLSTMFunction(torch.autograd.Function):
         # Weight gradients: [4H.. x TB] x [TB x F|H] with TB = T*B frames and a small
         # output.  As one GEMM the library fills 100-170 of 256 CUs (0.79 / 1.06 ms
         # at TB = 171k); split over G chunks of frames as a batched GEMM plus a sum
-        # of the G partial products they take 0.38 / 0.43 ms.
+        # of the G partial products they take 0.38 / 0.43 ms; the one-pass kernel of
+        # csrc/lstm_wgrad.hip replaces them where it is built (_weight_gradients).
         # h_{t-1}: the forward direction looks one frame back (frames 0..T-1 of its
         # zero-padded bf16 plane), the reverse one frame ahead (frames 2..T+1).
-        TB = T * B
-        g1, g2 = _chunks(TB, 16), _chunks(TB, 32)
-        dw_ih = _native.sum_leading(_bmm_f32(dg2.view(g1, TB // g1, 8 * H).transpose(1, 2),
-                                             xb.view(g1, TB // g1, F)))   # [2*4H, F]
-        dgd = dgb.view(g2, TB // g2, 2, 4 * H)
-        dw_hh = [_native.sum_leading(_bmm_f32(
-            dgd[:, :, d].transpose(1, 2),
-            (ybf[0, 0:T] if d == 0 else ybf[1, 2:T + 2]).reshape(g2, TB // g2, H)))
-            for d in range(2)]
+        dw_ih, dw_hh = _weight_gradients(dgb, xb, ybf, T, B, H, F)
         return dx, None, dw_ih[:4 * H], dw_hh[0], dw_ih[4 * H:], dw_hh[1], None
 
 
 def _weight_gradients(dgb, xb, ybf, T, B, H, F):
-    """dW_ih [2*4H, F] and dW_hh[d] [4H, H] from the gate gradients (see BiLSTMFunction.backward)"""
+    """dW_ih [2*4H, F] and dW_hh[d] [4H, H] from the gate gradients: the one-pass kernel
+    asr_lstm_wgrad_bf16 where it is built (H = 320; ASR_LSTM_WGRAD=0 switches it off), the
+    chunked library products otherwise — and for dW_ih of a layer whose input size is not H."""
+    if os.environ.get('ASR_LSTM_WGRAD', '1') != '0' and _native.lstm_wgrad_supported(H) \
+            and T * B * 16 * H < 2 ** 31:
+        if F == H:
+            dw_ih, dw_hh = _native.lstm_wgrad(dgb.view(T, B, 2, 4 * H), xb, ybf)
+            return dw_ih, [dw_hh[0], dw_hh[1]]
+        _, dw_hh = _native.lstm_wgrad(dgb.view(T, B, 2, 4 * H), None, ybf)
+        TB = T * B
+        g1 = _chunks(TB, 16)
+        dw_ih = _native.sum_leading(_bmm_f32(dgb.view(g1, TB // g1, 8 * H).transpose(1, 2),
+                                             xb.view(g1, TB // g1, F)))
+        return dw_ih, [dw_hh[0], dw_hh[1]]
+    return _weight_gradients_library(dgb, xb, ybf, T, B, H, F)
+
+
+def _weight_gradients_library(dgb, xb, ybf, T, B, H, F):
+    """the same as chunked library GEMMs (see BiLSTMFunction.backward)"""
     TB = T * B
     dg2 = dgb.view(TB, 8 * H)
     g1, g2 = _chunks(TB, 16), _chunks(TB, 32)

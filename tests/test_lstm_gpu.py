@@ -287,3 +287,53 @@ def test_layer_stack_matches_chained_layers(fused_bwd, monkeypatch):
     for a, b_ in zip(got, want):
         scale = float(b_.abs().max())
         assert float((a - b_).abs().max()) <= 2e-2 * scale + 1e-6
+
+
+@pytest.mark.parametrize('T,B,with_input', [
+    (1, 1, True),
+    (7, 5, True),              # fewer frames than one stage per chunk
+    (50, 33, True),
+    (50, 33, False),           # first-layer form: dW_hh only
+    (334, 96, True),
+    (334, 576, True),          # bench shape
+    (334, 576, False),
+])
+def test_weight_gradient_kernel_matches_fp32_products(T, B, with_input):
+    """asr_lstm_wgrad_bf16 (one pass over the gate gradients: LDS-DMA ring, transposing LDS
+    reads, MFMA) against the fp32 products of the same bf16 operands in torch, with exact
+    integer-valued data first (any mis-indexed fragment, swizzle or tail frame shows up as an
+    exact mismatch) and random data second (fp32 summation order differs: 2e-3 of the
+    largest entry)."""
+    from att_speech import _native
+    dev = torch.device('cuda:0')
+    H = 320
+    assert _native.lstm_wgrad_supported(H)
+    g = torch.Generator().manual_seed(T * 7 + B)
+    for exact in (True, False):
+        if exact:       # small integers: every product and partial sum is exact in fp32
+            dg = torch.randint(-2, 3, (T, B, 2, 4 * H), generator=g).float()
+            x = torch.randint(-2, 3, (T * B, H), generator=g).float()
+            y = torch.randint(-2, 3, (2, T + 2, B, H), generator=g).float()
+            if T * B > 4096:          # keep |sums| < 2^24
+                dg = dg * (torch.rand(T, B, 1, 1, generator=g) < 4096.0 / (T * B)).float()
+        else:
+            dg = torch.randn(T, B, 2, 4 * H, generator=g)
+            x = torch.randn(T * B, H, generator=g)
+            y = torch.randn(2, T + 2, B, H, generator=g)
+        dg, x, y = dg.to(dev, torch.bfloat16), x.to(dev, torch.bfloat16), y.to(dev, torch.bfloat16)
+        dw_ih, dw_hh = _native.lstm_wgrad(dg, x if with_input else None, y)
+        torch.cuda.synchronize()
+        a = dg.view(T * B, 8 * H).float()
+        want_hh = torch.stack([
+            a[:, :4 * H].t() @ y[0, 0:T].reshape(T * B, H).float(),
+            a[:, 4 * H:].t() @ y[1, 2:T + 2].reshape(T * B, H).float()])
+        pairs = [(dw_hh, want_hh)]
+        if with_input:
+            pairs.append((dw_ih, a.t() @ x.float()))
+        else:
+            assert dw_ih is None
+        for got, want in pairs:
+            if exact:
+                assert torch.equal(got, want), float((got - want).abs().max())
+            else:
+                assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max())

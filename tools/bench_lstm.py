@@ -58,3 +58,9 @@ if _native.lstm_fused_supported(B, H, backward=True):
     dxp = _native.lstm_bidir_bwd_fused(dy, whhT, wihT, lens, out[2], out[3])[1]
     print('backward, dy as planes %8.1f us' % timed(lambda: _native.lstm_bidir_bwd(dxp, whhT, lens, out[2], out[3], planes=True)))
 _native.lstm_check_errors()
+if _native.lstm_wgrad_supported(H):
+    from att_speech.modules.encoders import native_lstm
+    xb2 = x.view(T * B, H)
+    print('weight grads, library  %8.1f us' % timed(lambda: native_lstm._weight_gradients_library(dgb, xb2, out[1], T, B, H, H)))
+    print('weight grads, kernel   %8.1f us' % timed(lambda: _native.lstm_wgrad(dgb, xb2, out[1])))
+    print('  dW_hh only           %8.1f us' % timed(lambda: _native.lstm_wgrad(dgb, None, out[1])))
