@@ -144,8 +144,10 @@ class DeepSpeech2(BaseEncoder):
                     warnings.warn('DeepSpeech2: the second convolution is not the 32->32 7x7 '
                                   'stride-(3,1) shape csrc/conv.hip is built for; using torch / MIOpen')
                 y2 = run_conv(c2, x, with_bias=False, keep_bf16=True)
+            # the native LSTM rounds its input to bf16 first thing: hand it bf16 straight away
+            # (half the bytes written here, no cast pass, bf16 gradient coming back)
             x = bn_hardtanh(y2, conv[4].batch_norm, conv[5], time_major=True, conv_bias=c2.bias,
-                            chan_sums=sums2)
+                            chan_sums=sums2, out_bf16=bf16 and self._rnn_takes_bf16(y2))
             return x.view(x.size(0), x.size(1), -1)                  # [T', B, C*F']
         if bf16:
             x = conv[5](conv[4](second_conv(conv[2](conv[1](conv[0](features))))))
@@ -154,6 +156,16 @@ class DeepSpeech2(BaseEncoder):
         # bs x c x t x f -> t x bs x (c x f)
         x = x.permute(2, 0, 1, 3).contiguous()
         return x.view(x.size(0), x.size(1), -1)
+
+    def _rnn_takes_bf16(self, x):
+        """the first recurrent layer is the hand-written bf16-operand LSTM reading its input
+        unmodified (ASR_LSTM_BF16_INPUT=0 keeps the fp32 hand-over)"""
+        import os
+        if os.environ.get('ASR_LSTM_BF16_INPUT', '1') == '0':
+            return False
+        first = next(iter(self.rnns._modules.values()), None)
+        return (isinstance(first, BatchRNN) and first._use_native(x) and not first.residual
+                and type(first.batch_norm.batch_norm).__name__ == 'Identity')
 
     def forward(self, features, features_lengths, spkids, ivectors=None,
                 characteristic_vectors=None, **kwargs):

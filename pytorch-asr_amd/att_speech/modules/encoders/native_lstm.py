@@ -63,6 +63,7 @@ class BiLSTMFunction(torch.autograd.Function):
         T, B, F = x.shape
         H = w_hh_f.shape[1]
         xb = x.reshape(T * B, F).to(torch.bfloat16)
+        ctx.x_bf16 = x.dtype == torch.bfloat16        # then the input gradient is bf16 too
         w_ih = torch.cat([w_ih_f, w_ih_r], 0).to(torch.bfloat16)        # [2*4H, F]
         whh = torch.stack([w_hh_f, w_hh_r], 0).to(torch.bfloat16).contiguous()
         y, ybf, gates, csave = _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, True)
@@ -81,7 +82,8 @@ class BiLSTMFunction(torch.autograd.Function):
         # K-major second operand: the library's kernel for it is faster here (probe 0.38 vs
         # 0.44 ms) than the one it picks for the row-major [8H, F] weight; the transpose is
         # a 1.6 MB copy
-        dx = _mm_f32(dg2, w_ih.t().contiguous().t()).view(T, B, F)
+        wk = w_ih.t().contiguous().t()
+        dx = (torch.mm(dg2, wk) if ctx.x_bf16 else _mm_f32(dg2, wk)).view(T, B, F)
         # Weight gradients: [4H.. x TB] x [TB x F|H] with TB = T*B frames and a small
         # output.  As one GEMM the library fills 100-170 of 256 CUs (0.79 / 1.06 ms
         # at TB = 171k); split over G chunks of frames as a batched GEMM plus a sum
@@ -139,6 +141,7 @@ class BiLSTMStackFunction(torch.autograd.Function):
         T, B, F = x.shape
         n = len(weights) // 4
         saved, xb = [], x.reshape(T * B, F).to(torch.bfloat16)
+        ctx.x_bf16 = x.dtype == torch.bfloat16        # then the input gradient is bf16 too
         for l in range(n):
             w_ih_f, w_hh_f, w_ih_r, w_hh_r = weights[4 * l:4 * l + 4]
             H = w_hh_f.shape[1]
@@ -178,7 +181,11 @@ class BiLSTMStackFunction(torch.autograd.Function):
                 dgb = _native.lstm_bidir_bwd(dy, whhT, lens_dev, gates, csave, planes=planes)
                 dy_next, planes_next = None, False
                 if need_dx:
-                    dy_next = _mm_f32(dgb.view(T * B, 8 * H), w_ih.t().contiguous().t()).view(T, B, F)
+                    wk = w_ih.t().contiguous().t()
+                    if l == 0 and ctx.x_bf16:
+                        dy_next = torch.mm(dgb.view(T * B, 8 * H), wk).view(T, B, F)
+                    else:
+                        dy_next = _mm_f32(dgb.view(T * B, 8 * H), wk).view(T, B, F)
             dw_ih, dw_hh = _weight_gradients(dgb, xb, ybf, T, B, H, F)
             grads[4 * l:4 * l + 4] = [dw_ih[:4 * H], dw_hh[0], dw_ih[4 * H:], dw_hh[1]]
             dy, planes = dy_next, planes_next

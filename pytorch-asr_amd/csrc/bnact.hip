@@ -371,6 +371,210 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_nhwc_kernel(BnParamsN p,
     }
 }
 
+// ---- the same three passes with EIGHT channels per thread (16-byte accesses on bf16
+// tensors; with four, i.e. 8 bytes per lane, the bf16 passes ran at 2.3-2.7 TB/s); plain
+// channels-last on both sides
+struct F8 { float v[8]; };
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+__device__ __forceinline__ F8 load8(const __bf16 *p) {
+    const bf16x8v t = *reinterpret_cast<const bf16x8v *>(p);
+    F8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (float)t[i];
+    return r;
+}
+__device__ __forceinline__ F8 load8(const float *p) {
+    const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+    return F8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ void store8(__bf16 *p, const F8 &a) {
+    bf16x8v t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (__bf16)a.v[i];
+    *reinterpret_cast<bf16x8v *>(p) = t;
+}
+__device__ __forceinline__ void store8(float *p, const F8 &a) {
+    reinterpret_cast<float4 *>(p)[0] = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    reinterpret_cast<float4 *>(p)[1] = make_float4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+// per-channel totals of a workgroup (8 channels per thread) -> two double atomics per channel
+__device__ __forceinline__ void nhwc_block_atomics8(const float (&s)[8], const float (&q)[8], int C,
+                                                    double *sums) {
+    __shared__ float rs8[256][9], rq8[256][9];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { rs8[threadIdx.x][i] = s[i]; rq8[threadIdx.x][i] = q[i]; }
+    __syncthreads();
+    const int CG = C / 8;
+    if ((int)threadIdx.x < C) {
+        const int cg = threadIdx.x >> 3, i = threadIdx.x & 7;
+        float a = 0.f, b = 0.f;
+        for (int t = cg; t < 256; t += CG) { a += rs8[t][i]; b += rq8[t][i]; }
+        atomicAdd(&sums[2 * threadIdx.x], (double)a);
+        atomicAdd(&sums[2 * threadIdx.x + 1], (double)b);
+    }
+}
+#define NHWC8_THREAD_SETUP(P_)                                                         \
+    const int CG = C / 8, PL = 256 / CG, c0 = 8 * ((int)threadIdx.x % CG),             \
+              pl = (int)threadIdx.x / CG;                                              \
+    const int64_t per = ((P_) + gridDim.x - 1) / gridDim.x;                            \
+    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < (P_) ? p0 + per : (P_)
+
+template <typename XT, typename OutT>
+__global__ __launch_bounds__(256) void bn_act_fwd_nhwc8_kernel(BnParamsN p, OutT *out) {
+    const XT *px = (const XT *)p.x;
+    const int C = p.C;
+    NHWC8_THREAD_SETUP(p.P);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = p.gamma[c0 + i] * p.invstd[c0 + i];
+        sh[i] = p.beta[c0 + i] - (p.mean[c0 + i] - (p.shift ? p.shift[c0 + i] : 0.f)) * sc[i];
+    }
+    auto one = [&](int64_t pix, const F8 &v) {
+        F8 y;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y.v[i] = fminf(fmaxf(fmaf(v.v[i], sc[i], sh[i]), p.lo), p.hi);
+        store8(out + pix * C + c0, y);
+    };
+    int64_t pix = p0 + pl;
+    for (; pix + PL < p1; pix += 2 * PL) {
+        const F8 v0 = load8(px + pix * C + c0), v1 = load8(px + (pix + PL) * C + c0);
+        one(pix, v0);
+        one(pix + PL, v1);
+    }
+    for (; pix < p1; pix += PL) one(pix, load8(px + pix * C + c0));
+}
+
+// MODE 0: sums[c] = { sum dyh, sum dyh * xhat };  MODE 1: dx
+template <typename XT, typename DyT, int MODE>
+__global__ __launch_bounds__(256) void bn_act_bwd_nhwc8_kernel(BnParamsN p, const DyT *dy, double *sums,
+                                                               double n, int training, XT *dx) {
+    const XT *px = (const XT *)p.x;
+    const int C = p.C;
+    NHWC8_THREAD_SETUP(p.P);
+    float m[8], is[8], g[8], be[8], k1[8], k2[8], s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        m[i] = p.mean[c0 + i] - (p.shift ? p.shift[c0 + i] : 0.f);
+        is[i] = p.invstd[c0 + i]; g[i] = p.gamma[c0 + i]; be[i] = p.beta[c0 + i];
+        k1[i] = MODE == 1 && training ? (float)(sums[2 * (c0 + i)] / n) : 0.f;
+        k2[i] = MODE == 1 && training ? (float)(sums[2 * (c0 + i) + 1] / n) : 0.f;
+        s[i] = q[i] = 0.f;
+    }
+    auto one = [&](int64_t pix, const F8 &v, const F8 &dv) {
+        F8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (v.v[i] - m[i]) * is[i];
+            const float y = fmaf(xh, g[i], be[i]);
+            const float d = (y > p.lo && y < p.hi) ? dv.v[i] : 0.f;
+            if (MODE == 0) { s[i] += d; q[i] += d * xh; }
+            else o.v[i] = g[i] * is[i] * (d - k1[i] - xh * k2[i]);
+        }
+        if (MODE == 1) store8(dx + pix * C + c0, o);
+    };
+    int64_t pix = p0 + pl;
+    for (; pix + PL < p1; pix += 2 * PL) {        // two pixels per trip: four loads in flight
+        const F8 v0 = load8(px + pix * C + c0), v1 = load8(px + (pix + PL) * C + c0);
+        const F8 d0 = load8(dy + pix * C + c0), d1 = load8(dy + (pix + PL) * C + c0);
+        one(pix, v0, d0);
+        one(pix + PL, v1, d1);
+    }
+    for (; pix < p1; pix += PL) one(pix, load8(px + pix * C + c0), load8(dy + pix * C + c0));
+    if (MODE == 0) nhwc_block_atomics8(s, q, C, sums);
+}
+
+// ---- channels-last x, TIME-MAJOR y / dy ([H][B][C][W], the LSTM stack's layout): per
+// (b, h) row the W x C block of x is the transpose of the C x W block of y.  The kernels
+// above with TM = 1 address y element-wise (4-byte accesses W elements apart: 2.2 TB/s);
+// these move rows of y / dy as whole contiguous 16- or 8-byte pieces and transpose through
+// an fp32 LDS tile of TMR rows (bank pattern: 4 W cg + w over a half-wave = 32 distinct
+// banks for W odd).  Same arithmetic, same accumulation order per thread.
+template <typename T>
+__device__ __forceinline__ void tm_row_to_lds(const T *row, float *tile, int CW, int it) {
+    const F4 v = load4(row + 4 * it);
+    *reinterpret_cast<float4 *>(tile + 4 * it) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+}
+
+template <typename XT, typename OutT>
+__global__ __launch_bounds__(256) void bn_act_fwd_nhwc_tm_kernel(BnParamsN p, OutT *out, int TMR) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const XT *px = (const XT *)p.x;
+    const int C = p.C, W = p.W, CW = C * W, CG = C / 4, Q = CW / 4;
+    const int c0 = 4 * ((int)threadIdx.x % CG);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = p.gamma[c0 + i] * p.invstd[c0 + i];
+        sh[i] = p.beta[c0 + i] - (p.mean[c0 + i] - (p.shift ? p.shift[c0 + i] : 0.f)) * sc[i];
+    }
+    const int64_t nrows = p.P / W;
+    for (int64_t r0 = (int64_t)blockIdx.x * TMR; r0 < nrows; r0 += (int64_t)gridDim.x * TMR) {
+        const int nr = nrows - r0 < TMR ? (int)(nrows - r0) : TMR;
+        for (int it = threadIdx.x; it < nr * W * CG; it += 256) {
+            const int j = it / CG, row = j / W, w = j - row * W;      // pixel j of the tile
+            const F4 v = load4(px + (r0 * W + j) * C + c0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                tile[row * CW + (c0 + i) * W + w] = fminf(fmaxf(fmaf(v.v[i], sc[i], sh[i]), p.lo), p.hi);
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < nr * Q; it += 256) {
+            const int row = it / Q, k = it - row * Q;
+            const int64_t r = r0 + row;
+            const int b = (int)(r / p.H), h = (int)(r - (int64_t)b * p.H);
+            const float4 t = *reinterpret_cast<const float4 *>(tile + row * CW + 4 * k);
+            store4(out + ((size_t)h * p.B + b) * CW + 4 * k, F4{{t.x, t.y, t.z, t.w}});
+        }
+        __syncthreads();
+    }
+}
+
+// MODE 0: sums[c] = { sum dyh, sum dyh * xhat };  MODE 1: dx
+template <typename XT, typename DyT, int MODE>
+__global__ __launch_bounds__(256) void bn_act_bwd_nhwc_tm_kernel(BnParamsN p, const DyT *dy, double *sums,
+                                                                 double n, int training, XT *dx, int TMR) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const XT *px = (const XT *)p.x;
+    const int C = p.C, W = p.W, CW = C * W, CG = C / 4, Q = CW / 4;
+    const int c0 = 4 * ((int)threadIdx.x % CG);
+    float m[4], is[4], g[4], be[4], k1[4], k2[4], s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m[i] = p.mean[c0 + i] - (p.shift ? p.shift[c0 + i] : 0.f);
+        is[i] = p.invstd[c0 + i]; g[i] = p.gamma[c0 + i]; be[i] = p.beta[c0 + i];
+        k1[i] = MODE == 1 && training ? (float)(sums[2 * (c0 + i)] / n) : 0.f;
+        k2[i] = MODE == 1 && training ? (float)(sums[2 * (c0 + i) + 1] / n) : 0.f;
+    }
+    const int64_t nrows = p.P / W;
+    for (int64_t r0 = (int64_t)blockIdx.x * TMR; r0 < nrows; r0 += (int64_t)gridDim.x * TMR) {
+        const int nr = nrows - r0 < TMR ? (int)(nrows - r0) : TMR;
+        for (int it = threadIdx.x; it < nr * Q; it += 256) {
+            const int row = it / Q, k = it - row * Q;
+            const int64_t r = r0 + row;
+            const int b = (int)(r / p.H), h = (int)(r - (int64_t)b * p.H);
+            tm_row_to_lds(dy + ((size_t)h * p.B + b) * CW, tile + row * CW, CW, k);
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < nr * W * CG; it += 256) {
+            const int j = it / CG, row = j / W, w = j - row * W;
+            const F4 v = load4(px + (r0 * W + j) * C + c0);
+            F4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xh = (v.v[i] - m[i]) * is[i];
+                const float y = fmaf(xh, g[i], be[i]);
+                const float d = (y > p.lo && y < p.hi) ? tile[row * CW + (c0 + i) * W + w] : 0.f;
+                if (MODE == 0) { s[i] += d; q[i] += d * xh; }
+                else o.v[i] = g[i] * is[i] * (d - k1[i] - xh * k2[i]);
+            }
+            if (MODE == 1) store4(dx + (r0 * W + j) * C + c0, o);
+        }
+        __syncthreads();
+    }
+    if (MODE == 0) nhwc_block_atomics(s, q, C, sums);
+}
+
 // dgamma, dbeta, and the gradient of the folded-in convolution bias: sum of dx over
 // all pixels = gamma*invstd*sum(dyh) with running statistics, exactly 0 with batch
 // statistics (sum of xhat is 0 by construction)
@@ -444,6 +648,24 @@ extern "C" int asr_bn_act_fwd_f32(const void *x, int x_bf16, const float *conv_b
         BnParamsN q;
         q.x = x; q.P = P; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma; q.beta = beta;
         q.mean = save_mean; q.invstd = save_invstd; q.shift = conv_bias; q.lo = lo; q.hi = hi;
+        // time-major output through the LDS transpose when a row of it is whole 16-byte pieces
+        const int cw = C * W, tmr = cw > 0 ? (48 * 1024 / (cw * 4) < 32 ? 48 * 1024 / (cw * 4) : 32) : 0;
+        if (out_time_major && cw % 8 == 0 && tmr >= 1) {
+            const int64_t rows = (int64_t)B * H;
+            const int g2 = (int)((rows + tmr - 1) / tmr < 2048 ? (rows + tmr - 1) / tmr : 2048);
+            const size_t lds = (size_t)tmr * cw * 4;
+#define ASR_BN_FWDT(XT, OT) \
+            hipLaunchKernelGGL((bn_act_fwd_nhwc_tm_kernel<XT, OT>), dim3(g2), dim3(256), lds, s, q, (OT *)out, tmr)
+            if (x_bf16) { if (out_bf16) ASR_BN_FWDT(__bf16, __bf16); else ASR_BN_FWDT(__bf16, float); }
+            else { if (out_bf16) ASR_BN_FWDT(float, __bf16); else ASR_BN_FWDT(float, float); }
+#undef ASR_BN_FWDT
+            return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+        }
+        if (!out_time_major && x_bf16 && C % 8 == 0 && 256 % (C / 8) == 0) {      // 16-byte accesses
+            if (out_bf16) hipLaunchKernelGGL((bn_act_fwd_nhwc8_kernel<__bf16, __bf16>), dim3(nwg), dim3(256), 0, s, q, (__bf16 *)out);
+            else hipLaunchKernelGGL((bn_act_fwd_nhwc8_kernel<__bf16, float>), dim3(nwg), dim3(256), 0, s, q, (float *)out);
+            return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+        }
 #define ASR_BN_FWDN(XT, OT, TMV) \
         hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<XT, OT, TMV>), dim3(nwg), dim3(256), 0, s, q, (OT *)out)
         if (x_bf16) {
@@ -494,6 +716,37 @@ extern "C" int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_b
         q.x = x; q.P = (int64_t)B * HW; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma;
         q.beta = beta; q.mean = save_mean; q.invstd = save_invstd; q.shift = conv_bias; q.lo = lo; q.hi = hi;
         const int nwg = (int)(q.P / 64 < 4096 ? (q.P / 64 > 0 ? q.P / 64 : 1) : 4096);
+        const int cw = C * W, tmr = cw > 0 ? (48 * 1024 / (cw * 4) < 32 ? 48 * 1024 / (cw * 4) : 32) : 0;
+        if (dy_time_major && cw % 8 == 0 && tmr >= 1) {
+            const int64_t rows = (int64_t)B * H;
+            const int g2 = (int)((rows + tmr - 1) / tmr < 2048 ? (rows + tmr - 1) / tmr : 2048);
+            const size_t lds = (size_t)tmr * cw * 4;
+#define ASR_BN_BWDT(XT, DT)                                                                          \
+            do {                                                                                     \
+                hipLaunchKernelGGL((bn_act_bwd_nhwc_tm_kernel<XT, DT, 0>), dim3(g2), dim3(256), lds, \
+                                   s, q, (const DT *)dy, sums, n, training, (XT *)dx, tmr);          \
+                hipLaunchKernelGGL((bn_act_bwd_nhwc_tm_kernel<XT, DT, 1>), dim3(g2), dim3(256), lds, \
+                                   s, q, (const DT *)dy, sums, n, training, (XT *)dx, tmr);          \
+            } while (0)
+            if (x_bf16) { if (dy_bf16) ASR_BN_BWDT(__bf16, __bf16); else ASR_BN_BWDT(__bf16, float); }
+            else { if (dy_bf16) ASR_BN_BWDT(float, __bf16); else ASR_BN_BWDT(float, float); }
+#undef ASR_BN_BWDT
+            hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
+            return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+        }
+        if (!dy_time_major && x_bf16 && C % 8 == 0 && 256 % (C / 8) == 0) {       // 16-byte accesses
+#define ASR_BN_BWD8(DT)                                                                            \
+            do {                                                                                   \
+                hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<__bf16, DT, 0>), dim3(nwg), dim3(256), 0, s, \
+                                   q, (const DT *)dy, sums, n, training, (__bf16 *)dx);            \
+                hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<__bf16, DT, 1>), dim3(nwg), dim3(256), 0, s, \
+                                   q, (const DT *)dy, sums, n, training, (__bf16 *)dx);            \
+            } while (0)
+            if (dy_bf16) ASR_BN_BWD8(__bf16); else ASR_BN_BWD8(float);
+#undef ASR_BN_BWD8
+            hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
+            return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+        }
 #define ASR_BN_BWDN(XT, DT, TMV)                                                                  \
         do {                                                                                      \
             hipLaunchKernelGGL((bn_act_bwd_reduce_nhwc_kernel<XT, DT, TMV>), dim3(nwg), dim3(256), \

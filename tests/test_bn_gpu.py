@@ -149,3 +149,49 @@ def test_bf16_channels_last_input():
     assert float((xg.grad.float().cpu() - xr.grad).abs().max()) <= 1e-2 * scale      # bf16 dx
     torch.testing.assert_close(bn.weight.grad.cpu(), ref_bn.weight.grad, rtol=2e-4, atol=1e-3)
     torch.testing.assert_close(bn.running_var.cpu(), ref_bn.running_var, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('time_major,out_bf16', [(False, True), (False, False), (True, True), (True, False)])
+@pytest.mark.parametrize('B,C,H,W', [(3, 32, 40, 17), (2, 32, 67, 11), (5, 16, 9, 8)])
+def test_bf16_input_all_output_forms(B, C, H, W, time_major, out_bf16):
+    """bf16 channels-last x through the 16-byte-access kernels (plain channels-last y / dy)
+    and the LDS-transposing ones (time-major y / dy), y and dy in fp32 or bf16: the forward
+    is the fp32 computation on the bf16-rounded x (rounded once more for bf16 y), the
+    gradients those of the fp32 computation with the same (rounded) dy."""
+    from att_speech.modules.encoders.native_bn import bn_hardtanh
+    torch.manual_seed(B * 31 + W)
+    dev = torch.device('cuda:0')
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C) * 8 + 0.5)
+        bn.bias.copy_(torch.randn(C) * 4 + 6)
+    act = nn.Hardtanh(0, 20)
+    xb = (torch.randn(B, C, H, W) * 1.5).to(torch.bfloat16)
+    dy = torch.randn(B, C, H, W)
+    if out_bf16:
+        dy = dy.to(torch.bfloat16).float()
+    ref_bn = copy.deepcopy(bn)
+    xr = xb.float().requires_grad_()
+    yr = act(ref_bn(xr))
+    yr.backward(dy)
+    bn.to(dev)
+    xg = xb.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = bn_hardtanh(xg, bn, act, time_major=time_major, out_bf16=out_bf16)
+    assert y.dtype == (torch.bfloat16 if out_bf16 else torch.float32)
+    dyg = dy.to(dev).to(y.dtype)
+    if time_major:
+        assert tuple(y.shape) == (H, B, C, W)
+        y.backward(dyg.permute(2, 0, 1, 3).contiguous())
+        y_cmp = y.permute(1, 2, 0, 3)
+    else:
+        y.backward(dyg.contiguous(memory_format=torch.channels_last))
+        y_cmp = y
+    if out_bf16:
+        assert torch.equal(y_cmp.detach().cpu(), yr.detach().to(torch.bfloat16)) or \
+            float((y_cmp.detach().float().cpu() - yr.detach()).abs().max()) <= 2 ** -7 * 20
+    else:
+        torch.testing.assert_close(y_cmp.detach().cpu(), yr.detach(), rtol=1e-5, atol=1e-4)
+    scale = float(xr.grad.abs().max())
+    assert float((xg.grad.float().cpu() - xr.grad).abs().max()) <= 1e-2 * scale      # bf16 dx
+    torch.testing.assert_close(bn.weight.grad.cpu(), ref_bn.weight.grad, rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(bn.bias.grad.cpu(), ref_bn.bias.grad, rtol=2e-4, atol=2e-3)
