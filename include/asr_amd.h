@@ -253,6 +253,13 @@ int asr_lstm_wgrad_bf16(const void *dgates_bf16, const void *x_bf16, const void 
                         int T, int B, int H, float *dw_ih, float *dw_hh,
                         void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Input gradient of one layer from the gate gradients: dx [T*B, H] f32 = dgates [T*B, 2*4H] ·
+ * w_ih [2*4H, H] (both bf16, w_ih = nn.LSTM weight_ih_l0 / _reverse stacked; input size == H).
+ * Replaces the library product behind asr_lstm_bidir_bwd_bf16.  Built for H = 320. */
+int asr_lstm_dgrad_supported(int H);
+int asr_lstm_dgrad_bf16(const void *dgates_bf16, const void *w_ih_bf16, int T, int B, int H,
+                        float *dx, void *stream);
+
 /* The same layer with the input projection fused into the persistent recurrence
  * (replaces the `x·W_ihᵀ` GEMM in front of asr_lstm_bidir_fwd_bf16 when the layer's input
  * size equals H, i.e. every BatchRNN after the first, encoder_utils.py:97-124):

@@ -67,6 +67,8 @@ _SIGNATURES = {
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'asr_lstm_fused_supported': (_i, [_i, _i]),
     'asr_lstm_wgrad_supported': (_i, [_i]),
+    'asr_lstm_dgrad_supported': (_i, [_i]),
+    'asr_lstm_dgrad_bf16': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'asr_lstm_wgrad_workspace_bytes': (_i64, [_i, _i, _i, _i]),
     'asr_lstm_wgrad_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_bidir_bwd_fused_bf16': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
@@ -342,6 +344,23 @@ def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True):
                                           _p(_lstm_err_flag(dev)), _stream()),
           'asr_lstm_bidir_fwd_fused_bf16')
     return y, ybf, gates, csave
+
+
+def lstm_dgrad_supported(H):
+    return bool(lib().asr_lstm_dgrad_supported(int(H)))
+
+
+def lstm_dgrad(dgates, w_ih_bf16):
+    """asr_lstm_dgrad_bf16: dgates [T,B,2,4H] bf16, w_ih [8H,H] bf16 -> dx [T,B,H] f32."""
+    dgates = _dev(dgates, torch.bfloat16, 'dgates')
+    w_ih_bf16 = _dev(w_ih_bf16, torch.bfloat16, 'w_ih')
+    T, B, H = dgates.shape[0], dgates.shape[1], dgates.shape[3] // 4
+    if tuple(w_ih_bf16.shape) != (8 * H, H):
+        raise ValueError('lstm_dgrad: w_ih must be [8H, H]')
+    dx = torch.empty((T, B, H), dtype=torch.float32, device=dgates.device)
+    check(lib().asr_lstm_dgrad_bf16(_p(dgates), _p(w_ih_bf16), T, B, H, _p(dx), _stream()),
+          'asr_lstm_dgrad_bf16')
+    return dx
 
 
 def lstm_wgrad_supported(H):

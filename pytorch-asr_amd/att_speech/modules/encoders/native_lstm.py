@@ -38,6 +38,18 @@ def _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, want_y):
     return _native.lstm_bidir_fwd(gx, whh, lens_dev, want_y=want_y)
 
 
+def _input_gradient(dgb, w_ih, T, B, H, F, bf16_out=False):
+    """dx [T,B,F] = dgates · W_ih: the hand-written product (csrc/lstm_dgrad.hip) for F == H
+    where it is built (ASR_LSTM_DGRAD=0: library GEMM), the library GEMM otherwise; bf16_out:
+    the gradient of a bf16 layer input (the first layer behind the conv front-end)."""
+    if (not bf16_out and F == H and os.environ.get('ASR_LSTM_DGRAD', '1') != '0'
+            and _native.lstm_dgrad_supported(H) and T * B * 16 * H < 2 ** 31 - 2 ** 20):
+        return _native.lstm_dgrad(dgb.view(T, B, 2, 4 * H), w_ih)
+    wk = w_ih.t().contiguous().t()
+    dg2 = dgb.view(T * B, 8 * H)
+    return (torch.mm(dg2, wk) if bf16_out else _mm_f32(dg2, wk)).view(T, B, F)
+
+
 def _chunks(n, target):
     """largest power of two <= target that divides n and leaves >= 2048 rows per chunk"""
     g = target
@@ -82,8 +94,7 @@ class BiLSTMFunction(torch.autograd.Function):
         # K-major second operand: the library's kernel for it is faster here (probe 0.38 vs
         # 0.44 ms) than the one it picks for the row-major [8H, F] weight; the transpose is
         # a 1.6 MB copy
-        wk = w_ih.t().contiguous().t()
-        dx = (torch.mm(dg2, wk) if ctx.x_bf16 else _mm_f32(dg2, wk)).view(T, B, F)
+        dx = _input_gradient(dgb, w_ih, T, B, H, F, bf16_out=ctx.x_bf16)
         # Weight gradients: [4H.. x TB] x [TB x F|H] with TB = T*B frames and a small
         # output.  As one GEMM the library fills 100-170 of 256 CUs (0.79 / 1.06 ms
         # at TB = 171k); split over G chunks of frames as a batched GEMM plus a sum
@@ -181,11 +192,7 @@ class BiLSTMStackFunction(torch.autograd.Function):
                 dgb = _native.lstm_bidir_bwd(dy, whhT, lens_dev, gates, csave, planes=planes)
                 dy_next, planes_next = None, False
                 if need_dx:
-                    wk = w_ih.t().contiguous().t()
-                    if l == 0 and ctx.x_bf16:
-                        dy_next = torch.mm(dgb.view(T * B, 8 * H), wk).view(T, B, F)
-                    else:
-                        dy_next = _mm_f32(dgb.view(T * B, 8 * H), wk).view(T, B, F)
+                    dy_next = _input_gradient(dgb, w_ih, T, B, H, F, bf16_out=l == 0 and ctx.x_bf16)
             dw_ih, dw_hh = _weight_gradients(dgb, xb, ybf, T, B, H, F)
             grads[4 * l:4 * l + 4] = [dw_ih[:4 * H], dw_hh[0], dw_ih[4 * H:], dw_hh[1]]
             dy, planes = dy_next, planes_next

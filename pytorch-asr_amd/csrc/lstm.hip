@@ -1752,7 +1752,8 @@ int lstm_bwd_impl(const float *dy, int dy_shared, const void *whhT_bf16, const v
         pk[1] = lstm_bwd_dx_kernel<KSV, 3>; }
         ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16)
 #undef ASR_PICK
-        const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (1ull << 31);   // 32-bit byte offsets
+        // 32-bit byte offsets (the fused kernel marks masked lanes with offset 2^31: half the range)
+        const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (fused ? (1ull << 31) : (1ull << 32));
         const size_t lds = (size_t)(H / 4) * 1024 + ASR_GLDS_BYTES + 16384 + (fused ? 24 * 1280 : 0);
         if (fits32 && (pk[2] || fused) && launch_persist(pk, p, B, H, lds, ctl_words, err_flag, s))
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;

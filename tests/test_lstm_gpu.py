@@ -337,3 +337,30 @@ def test_weight_gradient_kernel_matches_fp32_products(T, B, with_input):
                 assert torch.equal(got, want), float((got - want).abs().max())
             else:
                 assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('T,B', [(1, 1), (7, 5), (50, 33), (334, 96), (334, 576)])
+def test_input_gradient_kernel_matches_fp32_product(T, B):
+    """asr_lstm_dgrad_bf16 (dx = dgates · W_ih: LDS-DMA stages, swizzled row-major A through
+    ds_read_b128, k-major W_ih through transposing reads, MFMA) against the fp32 product of the
+    same bf16 operands: exact on small-integer data, 2e-3 of the largest entry on random data."""
+    from att_speech import _native
+    dev = torch.device('cuda:0')
+    H = 320
+    assert _native.lstm_dgrad_supported(H)
+    g = torch.Generator().manual_seed(T * 5 + B)
+    for exact in (True, False):
+        if exact:
+            dg = torch.randint(-2, 3, (T, B, 2, 4 * H), generator=g).float()
+            w = torch.randint(-2, 3, (8 * H, H), generator=g).float()
+        else:
+            dg = torch.randn(T, B, 2, 4 * H, generator=g)
+            w = torch.randn(8 * H, H, generator=g) * 0.05
+        dg, w = dg.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16)
+        dx = _native.lstm_dgrad(dg, w)
+        torch.cuda.synchronize()
+        want = (dg.view(T * B, 8 * H).float() @ w.float()).view(T, B, H)
+        if exact:
+            assert torch.equal(dx, want), float((dx - want).abs().max())
+        else:
+            assert float((dx - want).abs().max()) <= 2e-3 * float(want.abs().max())

@@ -64,3 +64,5 @@ if _native.lstm_wgrad_supported(H):
     print('weight grads, library  %8.1f us' % timed(lambda: native_lstm._weight_gradients_library(dgb, xb2, out[1], T, B, H, H)))
     print('weight grads, kernel   %8.1f us' % timed(lambda: _native.lstm_wgrad(dgb, xb2, out[1])))
     print('  dW_hh only           %8.1f us' % timed(lambda: _native.lstm_wgrad(dgb, None, out[1])))
+if _native.lstm_dgrad_supported(H):
+    print('dx kernel              %8.1f us' % timed(lambda: _native.lstm_dgrad(dgb, wih)))
