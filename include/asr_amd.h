@@ -262,18 +262,20 @@ int asr_lstm_dgrad_bf16(const void *dgates_bf16, const void *w_ih_bf16, int T, i
 
 /* The same layer with the input projection fused into the persistent recurrence
  * (replaces the `x·W_ihᵀ` GEMM in front of asr_lstm_bidir_fwd_bf16 when the layer's input
- * size equals H, i.e. every BatchRNN after the first, encoder_utils.py:97-124):
- *   x_bf16    [T,B,H] bf16 row-major layer input
- *   wih_bf16  [2 dir][4H][H] bf16, rows in gate order i,f,g,o (nn.LSTM weight_ih_l0 /
+ * size F equals H, i.e. every BatchRNN after the first, encoder_utils.py:97-124 — or, for
+ * H = 320, F = 352: the first layer behind the reference's conv front-end):
+ *   x_bf16    [T,B,F] bf16 row-major layer input
+ *   wih_bf16  [2 dir][4H][F] bf16, rows in gate order i,f,g,o (nn.LSTM weight_ih_l0 /
  *             weight_ih_l0_reverse stacked)
+ *   y         must be NULL when F != H (that variant writes y_bf16 only)
  * Pre-activations are accumulated in fp32 over both products (no bf16 rounding of
- * x·W_ihᵀ).  ASR_EUNSUPPORTED when bit 0 of asr_lstm_fused_supported(B, H) is clear (hidden
- * size not one of 64/128/256/320, persistent path switched off): the caller then uses the
- * GEMM + asr_lstm_bidir_fwd_bf16. */
-int asr_lstm_fused_supported(int B, int H);
+ * x·W_ihᵀ).  ASR_EUNSUPPORTED when bit 0 of asr_lstm_fused_supported(B, H, F) is clear
+ * (hidden size not one of 64/128/256/320, another input size, persistent path switched
+ * off): the caller then uses the GEMM + asr_lstm_bidir_fwd_bf16. */
+int asr_lstm_fused_supported(int B, int H, int F);
 int asr_lstm_bidir_fwd_fused_bf16(const void *x_bf16, const void *wih_bf16,
                                   const void *whh_bf16, const int32_t *lens,
-                                  int T, int B, int H, float *y, void *y_bf16,
+                                  int T, int B, int H, int F, float *y, void *y_bf16,
                                   void *gates_bf16, float *csave, void *workspace,
                                   int64_t workspace_bytes, uint32_t *err_flag, void *stream);
 

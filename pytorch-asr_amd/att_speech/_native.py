@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -65,7 +65,7 @@ _SIGNATURES = {
     'asr_lstm_workspace_bytes': (_i64, [_i, _i]),
     'asr_lstm_bidir_fwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'asr_lstm_bidir_bwd_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    'asr_lstm_fused_supported': (_i, [_i, _i]),
+    'asr_lstm_fused_supported': (_i, [_i, _i, _i]),
     'asr_lstm_wgrad_supported': (_i, [_i]),
     'asr_lstm_dgrad_supported': (_i, [_i]),
     'asr_lstm_dgrad_bf16': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -73,7 +73,7 @@ _SIGNATURES = {
     'asr_lstm_wgrad_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_bidir_bwd_fused_bf16': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
                                            _vp, _i64, _vp, _vp]),
-    'asr_lstm_bidir_fwd_fused_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'asr_lstm_bidir_fwd_fused_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'asr_bn_act_workspace_bytes': (_i64, [_i]),
     'asr_bn_act_fwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -315,22 +315,24 @@ def lstm_bidir_fwd(gx, whh_bf16, lens, want_y=True):
     return y, ybf, gates, csave
 
 
-def lstm_fused_supported(B, H, backward=False):
+def lstm_fused_supported(B, H, backward=False, F=None):
     """asr_lstm_fused_supported: can asr_lstm_bidir_fwd_fused_bf16 (bit 0) /
-    asr_lstm_bidir_bwd_fused_bf16 (bit 1) run this (batch, hidden)?"""
-    return bool(lib().asr_lstm_fused_supported(int(B), int(H)) & (2 if backward else 1))
+    asr_lstm_bidir_bwd_fused_bf16 (bit 1) run this (batch, hidden, input size)?"""
+    F = H if F is None else F
+    return bool(lib().asr_lstm_fused_supported(int(B), int(H), int(F)) & (2 if backward else 1))
 
 
 def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True):
-    """asr_lstm_bidir_fwd_fused_bf16: x [T,B,H] bf16, wih [2*4H,H] bf16, whh [2,4H,H] bf16
+    """asr_lstm_bidir_fwd_fused_bf16: x [T,B,F] bf16, wih [2*4H,F] bf16, whh [2,4H,H] bf16
     -> the outputs of lstm_bidir_fwd, the input projection computed inside the recurrence."""
     x_bf16 = _dev(x_bf16, torch.bfloat16, 'x')
     wih_bf16 = _dev(wih_bf16, torch.bfloat16, 'wih')
     whh_bf16 = _dev(whh_bf16, torch.bfloat16, 'whh')
     lens = _dev(lens, torch.int32, 'lens')
-    T, B, H = x_bf16.shape
-    if tuple(wih_bf16.shape) != (8 * H, H) or tuple(whh_bf16.shape) != (2, 4 * H, H):
-        raise ValueError('lstm_bidir_fwd_fused: the layer input size must equal the hidden size')
+    T, B, F = x_bf16.shape
+    H = whh_bf16.shape[-1]
+    if tuple(wih_bf16.shape) != (8 * H, F) or tuple(whh_bf16.shape) != (2, 4 * H, H):
+        raise ValueError('lstm_bidir_fwd_fused: wih must be [8H, F], whh [2, 4H, H]')
     L = lib()
     dev = x_bf16.device
     y = torch.empty((T, B, 2, H), dtype=torch.float32, device=dev) if want_y else None
@@ -339,7 +341,7 @@ def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True):
     csave = torch.empty((T, 2, B, H), dtype=torch.float32, device=dev)
     nbytes = L.asr_lstm_workspace_bytes(B, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(L.asr_lstm_bidir_fwd_fused_bf16(_p(x_bf16), _p(wih_bf16), _p(whh_bf16), _p(lens), T, B, H,
+    check(L.asr_lstm_bidir_fwd_fused_bf16(_p(x_bf16), _p(wih_bf16), _p(whh_bf16), _p(lens), T, B, H, F,
                                           _p(y), _p(ybf), _p(gates), _p(csave), _p(ws), nbytes,
                                           _p(_lstm_err_flag(dev)), _stream()),
           'asr_lstm_bidir_fwd_fused_bf16')

@@ -28,9 +28,11 @@ def _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, want_y):
     [T*B, 8H] product in HBM; ASR_LSTM_FUSED=0 restores the GEMM); otherwise x·W_ih is one
     GEMM, accumulated in fp32 and stored once as bf16 (ASR_GX_FP32=1 keeps fp32: the
     product is 1.75 GB in fp32 at B=512 and its write bounds the GEMM)."""
-    if (xb.shape[1] == H and os.environ.get('ASR_LSTM_FUSED', '1') != '0'
-            and _native.lstm_fused_supported(B, H)):
-        return _native.lstm_bidir_fwd_fused(xb.view(T, B, H), w_ih, whh, lens_dev, want_y=want_y)
+    F = xb.shape[1]
+    mode = os.environ.get('ASR_LSTM_FUSED', '1')         # 0: never, inner: only F == H layers
+    if (mode != '0' and (F == H or (not want_y and mode != 'inner'))
+            and _native.lstm_fused_supported(B, H, F=F)):
+        return _native.lstm_bidir_fwd_fused(xb.view(T, B, F), w_ih, whh, lens_dev, want_y=want_y)
     if os.environ.get('ASR_GX_FP32', '0') == '1':
         gx = _mm_f32(xb, w_ih.t()).view(T, B, 2, 4 * H)
     else:

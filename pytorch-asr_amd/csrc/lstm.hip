@@ -115,7 +115,7 @@ struct LstmFwdParams {
     const void *gx;         // [T,B,2,4H] x·W_ihᵀ, gate order i,f,g,o; float or (gx_bf16) __bf16
     int gx_bf16;
     const __bf16 *x;        // fused input projection (persistent kernel, F == H): x [T,B,H] bf16 row-major
-    const __bf16 *wih;      // ... and the fragment-major pack of W_ih [2*4 (dir,gate)][H rows][H cols]
+    const __bf16 *wih;      // ... and the fragment-major pack of W_ih [2*4 (dir,gate)][H rows][F cols]
     const __bf16 *whh;      // fragment-major pack of [2*4 (dir,gate)][H rows][H cols]
     const int32_t *lens;    // [B]
     int T, B, H;
@@ -565,9 +565,10 @@ struct LstmTeamCtl {
 // = more workgroups; the host picks the smallest tile whose grid still fits one
 // workgroup per CU).  Rows >= 8*NE of the 32-row MFMA tile are padding.
 //
-// XF = 1 fuses the input projection: instead of reading x·W_ihᵀ (`gx`, the output of a
+// XF > 0 (= the input size F / 16: the projection's k-steps) fuses the input projection: instead of reading x·W_ihᵀ (`gx`, the output of a
 // [T·B, F] x [F, 8H] library GEMM: 0.37 ms and 2 GB of HBM traffic per layer at B=576) the
-// workgroup keeps its W_ih slice in registers next to W_hh (F == H) and multiplies the x_t
+// workgroup keeps its W_ih slice in registers next to W_hh (F == H, or the first layer's
+// F = 352 behind the conv front-end: 22 k-steps) and multiplies the x_t
 // tile itself — x_t does not depend on the recurrence, so waves 4-7 do it while the
 // workgroup waits for the team's counter and waves 0-3 while the hand-off tile is in
 // flight: both windows (911 / 1036 cycles at B=512) were idle.  The sum x_t·W_ih + h·W_hh
@@ -578,7 +579,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     __bf16 *a_lds = reinterpret_cast<__bf16 *>(smem);                       // KS KiB
     float (*g_lds)[32][65] = reinterpret_cast<float (*)[32][65]>(smem + KS * 1024);
     __bf16 *h_lds = reinterpret_cast<__bf16 *>(smem + KS * 1024 + ASR_GLDS_BYTES);   // 4 KiB
-    __bf16 *x_lds = reinterpret_cast<__bf16 *>(smem + KS * 1024 + ASR_GLDS_BYTES + 4096);   // XF: KS KiB
+    __bf16 *x_lds = reinterpret_cast<__bf16 *>(smem + KS * 1024 + ASR_GLDS_BYTES + 4096);   // XF KiB
+    constexpr int KX = XF > 0 ? XF : 1;
     __shared__ int dead_s;
     const int H = p.H, B = p.B, T = p.T;
     int jt = blockIdx.x, btile = blockIdx.y + ctl.bt0, dir = blockIdx.z;
@@ -603,46 +605,53 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     for (int i = tid; i < KS * 64; i += 512)                            // (the tile's too: never loaded)
         reinterpret_cast<u32x4 *>(a_lds)[i] = u32x4{0u, 0u, 0u, 0u};
     if constexpr (XF)
-        for (int i = tid; i < KS * 64; i += 512)
+        for (int i = tid; i < KX * 64; i += 512)
             reinterpret_cast<u32x4 *>(x_lds)[i] = u32x4{0u, 0u, 0u, 0u};
 
-    bf16x8 fb[KS], fx[XF ? KS : 1];
+    bf16x8 fb[KS], fx[KX];
     {
         const size_t wo = ((size_t)(dir * 4 + gate) * H * H) + ((size_t)(2 * jt + js) * KS * 64 + lane) * 8;
 #pragma unroll
         for (int k = 0; k < KS; ++k) fb[k] = *reinterpret_cast<const bf16x8 *>(p.whh + wo + k * 512);
-        if constexpr (XF) {
+        if constexpr (XF) {       // W_ih pack: [2*4][H rows][16*KX cols], fragment-major
+            const size_t wox = ((size_t)(dir * 4 + gate) * H * (16 * KX)) + ((size_t)(2 * jt + js) * KX * 64 + lane) * 8;
 #pragma unroll
-            for (int k = 0; k < KS; ++k) fx[k] = *reinterpret_cast<const bf16x8 *>(p.wih + wo + k * 512);
+            for (int k = 0; k < KX; ++k) fx[k] = *reinterpret_cast<const bf16x8 *>(p.wih + wox + k * 512);
         }
     }
     const __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc(
         p.hbuf, 0, (int)(2 * 2 * Bp * H * 2), 0x00020000);
+    const rsrc_words hresD = raw_rsrc(p.hbuf, (unsigned)(2 * 2 * Bp * H * 2));
 
     // the thread's four (row, col) elements: row = e*8 + wave, col = lane
-    const int col = lane, j = j0 + col;
+    const int col = lane;
     float c[NE];
     __bf16 hq[NE];
     int len[NE];
-    // Every per-step global access of the pointwise part goes through a raw buffer with a
-    // per-element 32-bit byte offset computed ONCE here plus a wave-uniform frame offset in
-    // an SGPR: no 64-bit address arithmetic in the step loop, and masked rows simply carry
-    // an out-of-range offset (stores dropped).  The host checks every tensor is < 4 GiB.
+    // Every per-step global access of the pointwise part goes through a raw buffer: the
+    // lane's column as the only per-lane offset (4, 2 or 8 bytes per column), the row and
+    // frame parts — wave-uniform: a wave's rows are b0 + 8 e + wave — in SGPRs; no 64-bit
+    // address arithmetic in the step loop, and masked rows simply carry an out-of-range lane
+    // offset (stores dropped).  The host checks every tensor is < 4 GiB.
     typedef unsigned int u32;
     constexpr u32 OOBV = 0xFFFFFFFFu;
     constexpr u32 GXE = GXB ? 2u : 4u;
-    u32 vgx[NE], vy[NE], vyb[NE], vcs[NE];     // gate records: 2 * vcs
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const u32 l4 = (u32)col * 4u, l2 = (u32)col * 2u;
+    u32 sgx[NE], sy[NE], syb[NE], scs[NE];     // row parts (bytes); gate records: 2 * scs
+    bool inb[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-        const int b = b0 + e * 8 + wave;
+        const int b = b0 + e * 8 + wv;
         const int bc = b < B ? b : B - 1;
+        inb[e] = b < B;
         c[e] = 0.f;
         hq[e] = (__bf16)0.f;
-        len[e] = b < B ? p.lens[b] : 0;
-        vgx[e] = (u32)((bc * 2 + dir) * 4 * H + j) * GXE;
-        vy[e] = b < B ? (u32)((b * 2 + dir) * H + j) * 4u : OOBV;
-        vyb[e] = b < B ? (u32)(((size_t)(dir * (T + 2) + 1) * B + b) * H + j) * 2u : OOBV;
-        vcs[e] = b < B ? (u32)((dir * B + b) * H + j) * 4u : OOBV;
+        len[e] = __builtin_amdgcn_readfirstlane(b < B ? p.lens[bc] : 0);
+        sgx[e] = (u32)((bc * 2 + dir) * 4 * H + j0) * GXE;
+        sy[e] = (u32)((b * 2 + dir) * H + j0) * 4u;
+        syb[e] = (u32)(((size_t)(dir * (T + 2) + 1) * B + b) * H + j0) * 2u;
+        scs[e] = (u32)((dir * B + b) * H + j0) * 4u;
     }
     const u32 fgx = (u32)B * 8u * H * GXE, fy = (u32)B * 2u * H * 4u, fyb = (u32)B * H * 2u;
     const u32 fcs = (u32)B * 2u * H * 4u, fg = (u32)B * 2u * H * 8u;
@@ -653,17 +662,17 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     // exactly the destination pattern of one `buffer_load_dwordx4 ... lds`; lanes of the
     // tile's padding rows carry an out-of-range offset and write zeros.  Wave w moves
     // k-steps w, w + 8, w + 16.
-    const rsrc_words xD = raw_rsrc(p.x, XF ? (unsigned)((u32)T * B * H * 2u) : 0u);
-    const u32 fx_frame = (u32)B * H * 2u;
+    const rsrc_words xD = raw_rsrc(p.x, XF ? (unsigned)((u32)T * B * (16 * KX) * 2u) : 0u);
+    const u32 fx_frame = (u32)B * (16 * KX) * 2u;
     u32 vx = 0x80000000u;
     if constexpr (XF) {
         const int xr = lane & 31, b = b0 + xr < B ? b0 + xr : B - 1;
-        if (xr < 8 * NE) vx = (u32)(b * H + 16 * wave + 8 * (lane >> 5)) * 2u;
+        if (xr < 8 * NE) vx = (u32)(b * (16 * KX) + 16 * wv + 8 * (lane >> 5)) * 2u;
     }
     auto x_dma = [&](int tq) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            if (wave + 8 * i < KS)
+            if (wave + 8 * i < KX)
                 dma16_s(xD, (unsigned)__builtin_amdgcn_readfirstlane(
                                 (int)(lds_addr(x_lds) + (unsigned)(wave + 8 * i) * 1024u)),
                         vx + (u32)i * 256u, (u32)__builtin_amdgcn_readfirstlane((int)((u32)tq * fx_frame)));
@@ -697,18 +706,25 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
 #pragma unroll
             for (int e = 0; e < NE; ++e)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pgx[e][g] = ld_gx(vgx[e], (u32)t0 * fgx + (u32)g * H * GXE);
+                for (int g = 0; g < 4; ++g) pgx[e][g] = ld_gx((u32)col * GXE, sgx[e] + (u32)t0 * fgx + (u32)g * H * GXE);
         }
     }
-    constexpr int AD = XF ? 2 : 4;       // A fragments in flight (registers are short with two weight slices)
+    // A fragments in flight (registers are short with two weight slices: read one k-step ahead
+    // there — one by one the chain pays the LDS latency per MFMA, 3x the window it has to fit).
+    // The first layer's variant (22 input k-steps) writes no fp32 y: it is never the last layer
+    // of a stack.
+    constexpr int AD = XF ? 2 : 4;
+    constexpr bool NOY = XF > KS;
     f32x16 accx;                 // XF: x_t · W_ih of this wave's (gate, column half)
     auto x_mfma = [&]() {
 #pragma unroll
         for (int i = 0; i < 16; ++i) accx[i] = 0.f;
         const bf16x8 *xl = reinterpret_cast<const bf16x8 *>(x_lds) + lane;
-        if constexpr (XF) accx = mfma_chain<0, KS, AD>(xl, fx, accx);
+        if constexpr (XF) accx = mfma_chain<0, KX, AD>(xl, fx, accx);
     };
-    float sog[NE][4] = {}, soh[NE] = {}, sc[NE] = {};
+    u32x2 sog[NE] = {};
+    float soh[NE] = {}, sc[NE] = {};
+    __bf16 shq[NE] = {};                 // NOY: the bf16 output of the step (0 on padding frames)
     bool sact[NE] = {};
     int st = 0;
     // live == false (the first step has nothing to store yet): every offset out of range,
@@ -717,15 +733,17 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         const u32 ust = (u32)st;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, soh[e]), yR,
-                                                  live ? vy[e] : OOBV, ust * fy, 0);
+            const bool on = live && inb[e];
+            if constexpr (!NOY)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, soh[e]), yR,
+                                                      on ? l4 : OOBV, ust * fy + sy[e], 0);
             __builtin_amdgcn_raw_buffer_store_b16(
-                (short)__builtin_bit_cast(unsigned short, (__bf16)soh[e]), ybR,
-                live ? vyb[e] : OOBV, ust * fyb, 0);
+                (short)__builtin_bit_cast(unsigned short, NOY ? shq[e] : (__bf16)soh[e]), ybR,
+                on ? l2 : OOBV, ust * fyb + syb[e], 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sc[e]), csR,
-                                                  live ? vcs[e] : OOBV, ust * fcs, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(pack_gates(sog[e]), gR,
-                                                  live && sact[e] ? vcs[e] * 2u : OOBV, ust * fg, 0);
+                                                  on ? l4 : OOBV, ust * fcs + scs[e], 0);
+            __builtin_amdgcn_raw_buffer_store_b64(sog[e], gR,
+                                                  on && sact[e] ? l4 * 2u : OOBV, ust * fg + scs[e] * 2u, 0);
         }
     };
 
@@ -739,8 +757,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             asm volatile("" : "+v"(fb[k]));
-            asm volatile("" : "+v"(fx[k]));
         }
+#pragma unroll
+        for (int k = 0; k < KX; ++k) asm volatile("" : "+v"(fx[k]));
 #pragma unroll
         for (int e = 0; e < NE; ++e) asm volatile("" : "+v"(len[e]));
     }
@@ -759,8 +778,21 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         // (only the 2 * 8*NE chunks of a k-step that carry real batch rows move; the
         // padding rows of the 32-row MFMA tile stay zero in LDS)
         constexpr int RL = 8 * NE, CPK = 2 * RL;
-        constexpr int CHO = (KS - 4) * CPK, NI = (CHO + 511) / 512;
+        constexpr int CHO = (KS - 4) * CPK, NI = XF ? 0 : (CHO + 511) / 512;
         u32x4 tmp[NI > 0 ? NI : 1];
+        if constexpr (XF) {
+            // with two weight slices in registers there is none left to stage the tile in: it
+            // comes global -> LDS by LDS-DMA (the hand-off buffer is fragment-major, 1 KiB per
+            // k-step, lane-linear on both sides; padding rows read out of range = zeros)
+            const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H +
+                                              (size_t)btile * KS * 512) * 2);
+            const u32 voffT = (lane & 31) < RL ? (u32)lane * 16u : 0x80000000u;
+            for (int ko = wv; ko < KS - 4; ko += 8) {
+                const int kk = ko < 4 * jt ? ko : ko + 4;
+                dma16_sc1(hresD, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr(a_lds) + (unsigned)kk * 1024u)),
+                          voffT, (unsigned)__builtin_amdgcn_readfirstlane((int)(base + (unsigned)kk * 1024u)));
+            }
+        }
         if constexpr (NI > 0) {
             const unsigned base = (unsigned)((((size_t)(step & 1) * 2 + dir) * Bp * H +
                                               (size_t)btile * KS * 512) * 2);
@@ -776,15 +808,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         if (tid < 256)
             reinterpret_cast<u32x4 *>(a_lds)[(4 * jt + (tid >> 6)) * 64 + (tid & 63)] =
                 reinterpret_cast<const u32x4 *>(h_lds)[tid];
-        if constexpr (XF) if (wave < 4) x_mfma();           // under the hand-off tile's flight
+        if constexpr (XF) {
+            if (wave < 4) x_mfma();                         // under the hand-off tile's flight
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tile
+        }
         if constexpr (NI > 0) {
-            // (XF: wait for the tile on every path, not only inside the `co < CHO` branch —
-            // otherwise the compiler protects the MFMA accumulators that reuse these
-            // registers with a vmcnt(0) placed behind the x_{t+1} DMA it cannot see)
-            if constexpr (XF) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(tmp[i]));
-            }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int co = i * 512 + tid;
@@ -810,7 +838,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
                 for (int e = 0; e < NE; ++e)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        ngx[e][g] = ld_gx(vgx[e], (u32)tn * fgx + (u32)g * H * GXE);
+                        ngx[e][g] = ld_gx((u32)col * GXE, sgx[e] + (u32)tn * fgx + (u32)g * H * GXE);
             }
         }
         {
@@ -842,15 +870,18 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
             const int row = e * 8 + wave;
             sact[e] = t < len[e];
             if (sact[e]) {
-                float pre[4], cn;
+                float pre[4], cn, og[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pre[g] = XF ? g_lds[g][row][col] : g_lds[g][row][col] + pgx[XF ? 0 : e][g];
-                lstm_cell_fwd(pre, c[e], sog[e], cn, soh[e]);
+                lstm_cell_fwd(pre, c[e], og, cn, soh[e]);
+                sog[e] = pack_gates(og);
                 c[e] = cn;
                 if (dead) soh[e] = __builtin_nanf("");
                 hq[e] = (__bf16)soh[e];
+                shq[e] = hq[e];
             } else {
                 soh[e] = 0.f;
+                shq[e] = (__bf16)0.f;
             }
             sc[e] = c[e];
             h_lds[(((col >> 4) * 64) + row + 32 * ((col >> 3) & 1)) * 8 + (col & 7)] = hq[e];
@@ -1561,11 +1592,11 @@ extern "C" int64_t asr_lstm_workspace_bytes(int B, int H) {
     const int64_t Bp = plane_rows(B);
     // (forward with the fused input projection: a second packed matrix, W_ih)
     return (int64_t)2 * 2 * Bp * 4 * H * 2 + (int64_t)2 * B * H * 4 +
-           (int64_t)2 * 2 * 4 * H * H * 2 + 256 + ctl_bytes(B);
+           (int64_t)2 * 4 * H * H * 2 + (int64_t)2 * 4 * H * (H + 64) * 2 + 256 + ctl_bytes(B);
 }
 
 namespace {
-int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *wih_bf16,
+int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *wih_bf16, int F,
                   const void *whh_bf16, const int32_t *lens, int T, int B, int H,
                   float *y, void *y_bf16, void *gates_bf16, float *csave,
                   void *workspace, int64_t workspace_bytes, uint32_t *err_flag, void *stream);
@@ -1578,24 +1609,27 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
                                        void *workspace, int64_t workspace_bytes,
                                        uint32_t *err_flag, void *stream) {
     if (!gx) return ASR_EINVAL;
-    return lstm_fwd_impl(gx, gx_bf16, nullptr, nullptr, whh_bf16, lens, T, B, H, y, y_bf16,
+    return lstm_fwd_impl(gx, gx_bf16, nullptr, nullptr, 0, whh_bf16, lens, T, B, H, y, y_bf16,
                          gates_bf16, csave, workspace, workspace_bytes, err_flag, stream);
 }
 
 extern "C" int asr_lstm_bidir_fwd_fused_bf16(const void *x_bf16, const void *wih_bf16,
                                              const void *whh_bf16, const int32_t *lens,
-                                             int T, int B, int H, float *y, void *y_bf16,
+                                             int T, int B, int H, int F, float *y, void *y_bf16,
                                              void *gates_bf16, float *csave, void *workspace,
                                              int64_t workspace_bytes, uint32_t *err_flag,
                                              void *stream) {
     if (!x_bf16 || !wih_bf16) return ASR_EINVAL;
-    return lstm_fwd_impl(nullptr, 1, x_bf16, wih_bf16, whh_bf16, lens, T, B, H, y, y_bf16,
+    return lstm_fwd_impl(nullptr, 1, x_bf16, wih_bf16, F, whh_bf16, lens, T, B, H, y, y_bf16,
                          gates_bf16, csave, workspace, workspace_bytes, err_flag, stream);
 }
 
-extern "C" int asr_lstm_fused_supported(int B, int H) {
+extern "C" int asr_lstm_fused_supported(int B, int H, int F) {
     if (!persist_enabled() || B <= 0) return 0;
     if (H != 64 && H != 128 && H != 256 && H != 320) return 0;
+    // input size: the hidden size, or (H = 320) the 352 features of the conv front-end —
+    // forward only
+    if (F != H) return (H == 320 && F == 352 && cu_count() >= 2 * (H / 64)) ? 1 : 0;
     const int cus = cu_count(), njt = H / 64;
     if (cus < 2 * njt) return 0;
     // bit 0: forward (input projection); bit 1: backward (input gradient) — its kernel has no
@@ -1604,7 +1638,7 @@ extern "C" int asr_lstm_fused_supported(int B, int H) {
 }
 
 namespace {
-int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *wih_bf16,
+int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *wih_bf16, int F,
                   const void *whh_bf16, const int32_t *lens, int T, int B, int H,
                   float *y, void *y_bf16, void *gates_bf16, float *csave,
                   void *workspace, int64_t workspace_bytes, uint32_t *err_flag, void *stream) {
@@ -1613,8 +1647,9 @@ int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *w
     if (T == 0) return ASR_OK;
     if (!whh_bf16 || !lens || !y_bf16 || !gates_bf16 || !csave || !workspace)
         return ASR_EINVAL;
-    if (fused && (!(asr_lstm_fused_supported(B, H) & 1) || (uint64_t)T * B * H * 2 >= (1ull << 31)))
+    if (fused && (!(asr_lstm_fused_supported(B, H, F) & 1) || (uint64_t)T * B * F * 2 >= (1ull << 31)))
         return ASR_EUNSUPPORTED;
+    if (fused && F != H && y) return ASR_EINVAL;      // that variant writes the bf16 outputs only
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmFwdParams p;
@@ -1636,9 +1671,9 @@ int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *w
     // [2 dir x 4 gates] matrices of H x H (rows = hidden unit, cols = k)
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
                        (const __bf16 *)whh_bf16, wpack, 8, H, H, 0);
-    if (fused)          // wih_bf16: [2 dir][4H rows (gate-major)][H cols] row-major, F == H
+    if (fused)          // wih_bf16: [2 dir][4H rows (gate-major)][F cols] row-major
         hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
-                           (const __bf16 *)wih_bf16, wpack + (size_t)8 * H * H, 8, H, H, 0);
+                           (const __bf16 *)wih_bf16, wpack + (size_t)8 * H * H, 8, H, F, 0);
     if (persist_enabled()) {
         unsigned *ctl_words = (unsigned *)((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B));
         zero_async(ctl_words, (size_t)ctl_bytes(B), s);
@@ -1650,14 +1685,18 @@ int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *w
                pk[2] = lstm_fwd_persist_kernel<KSV, 4, 0, 0>; } }
         ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16) ASR_PICK(24) ASR_PICK(32)   // 48: W_hh slice spills
 #undef ASR_PICK
-#define ASR_PICK(KSV) if (H == 16 * KSV && fused) { pk[0] = lstm_fwd_persist_kernel<KSV, 2, 1, 1>; \
-        pk[1] = lstm_fwd_persist_kernel<KSV, 3, 1, 1>; pk[2] = lstm_fwd_persist_kernel<KSV, 4, 1, 1>; }
+#define ASR_PICK(KSV) if (H == 16 * KSV && fused && F == H) { pk[0] = lstm_fwd_persist_kernel<KSV, 2, 1, KSV>; \
+        pk[1] = lstm_fwd_persist_kernel<KSV, 3, 1, KSV>; pk[2] = lstm_fwd_persist_kernel<KSV, 4, 1, KSV>; }
         ASR_PICK(20) ASR_PICK(4) ASR_PICK(8) ASR_PICK(16)     // two weight slices in registers
 #undef ASR_PICK
+        if (H == 320 && fused && F == 352) {                  // the first layer behind the conv front-end
+            pk[0] = lstm_fwd_persist_kernel<20, 2, 1, 22>; pk[1] = lstm_fwd_persist_kernel<20, 3, 1, 22>;
+            pk[2] = lstm_fwd_persist_kernel<20, 4, 1, 22>;
+        }
         // the persistent kernel addresses gx / y / gates / ... with 32-bit byte offsets
         const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (1ull << 32) &&
                             (uint64_t)2 * (T + 2) * B * H * 2 < (1ull << 32);
-        if (fits32 && pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 * (fused ? 2 : 1) + ASR_GLDS_BYTES + 4096,
+        if (fits32 && pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + (fused ? (size_t)(F / 16) * 1024 : 0) + ASR_GLDS_BYTES + 4096,
                                  ctl_words, err_flag, s))
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
@@ -1719,7 +1758,7 @@ int lstm_bwd_impl(const float *dy, int dy_shared, const void *whhT_bf16, const v
     if (T == 0) return ASR_OK;
     if (!dy || !whhT_bf16 || !lens || !gates_bf16 || !csave || !dgates_bf16 || !workspace)
         return ASR_EINVAL;
-    if (fused && !(asr_lstm_fused_supported(B, H) & 2)) return ASR_EUNSUPPORTED;
+    if (fused && !(asr_lstm_fused_supported(B, H, H) & 2)) return ASR_EUNSUPPORTED;
     if (workspace_bytes < asr_lstm_workspace_bytes(B, H)) return ASR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     LstmBwdParams p;
