@@ -1500,6 +1500,33 @@ __global__ void zero_bytes_kernel(uint32_t *p, size_t n) {
     for (; i < n; i += stride) p[i] = 0u;
 }
 
+// several ranges in ONE launch (a forward call clears its state buffers, the four pad frames
+// of y_bf16 and the team counters: six 5-us launches per layer and direction pair otherwise)
+struct ZeroRanges { uint32_t *p[6]; size_t n[6]; int count; };
+__global__ void zero_ranges_kernel(ZeroRanges z) {
+    for (int r = 0; r < z.count; ++r) {
+        size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const size_t stride = (size_t)gridDim.x * blockDim.x;
+        for (; i < z.n[r]; i += stride) z.p[r][i] = 0u;
+    }
+}
+struct ZeroList {
+    ZeroRanges z;
+    ZeroList() { z.count = 0; }
+    void add(void *p, size_t bytes) {
+        if (bytes / 4 == 0) return;
+        z.p[z.count] = (uint32_t *)p; z.n[z.count] = bytes / 4; ++z.count;
+    }
+    void launch(hipStream_t s) {
+        if (!z.count) return;
+        size_t most = 0;
+        for (int r = 0; r < z.count; ++r) most = z.n[r] > most ? z.n[r] : most;
+        int blocks = (int)((most + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(zero_ranges_kernel, dim3(blocks), dim3(256), 0, s, z);
+    }
+};
+
 inline void zero_async(void *p, size_t bytes, hipStream_t s) {
     const size_t n = bytes / 4;
     if (!n) return;
@@ -1662,12 +1689,16 @@ int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *w
     p.hbuf = (__bf16 *)workspace;
     p.cbuf = (float *)((char *)workspace + hbytes);
     p.y = y; p.ybf = (__bf16 *)y_bf16; p.gates = (u32x2 *)gates_bf16; p.csave = csave;
-    zero_async(workspace, hbytes + cbytes, s);
+    ZeroList zl;
+    zl.add(workspace, hbytes + cbytes);
     // the two pad frames of every direction of y_bf16
     for (int d = 0; d < 2; ++d) {
-        zero_async(p.ybf + (size_t)d * (T + 2) * B * H, (size_t)B * H * 2, s);
-        zero_async(p.ybf + ((size_t)d * (T + 2) + T + 1) * B * H, (size_t)B * H * 2, s);
+        zl.add(p.ybf + (size_t)d * (T + 2) * B * H, (size_t)B * H * 2);
+        zl.add(p.ybf + ((size_t)d * (T + 2) + T + 1) * B * H, (size_t)B * H * 2);
     }
+    if (persist_enabled())
+        zl.add((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B), (size_t)ctl_bytes(B));
+    zl.launch(s);
     // [2 dir x 4 gates] matrices of H x H (rows = hidden unit, cols = k)
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
                        (const __bf16 *)whh_bf16, wpack, 8, H, H, 0);
@@ -1676,7 +1707,6 @@ int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *w
                            (const __bf16 *)wih_bf16, wpack + (size_t)8 * H * H, 8, H, F, 0);
     if (persist_enabled()) {
         unsigned *ctl_words = (unsigned *)((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B));
-        zero_async(ctl_words, (size_t)ctl_bytes(B), s);
         void (*pk[3])(LstmFwdParams, LstmTeamCtl) = {nullptr, nullptr, nullptr};
 #define ASR_PICK(KSV) if (H == 16 * KSV && !fused) {                                           \
         if (gx_bf16) { pk[0] = lstm_fwd_persist_kernel<KSV, 2, 1, 0>; pk[1] = lstm_fwd_persist_kernel<KSV, 3, 1, 0>; \
@@ -1772,7 +1802,13 @@ int lstm_bwd_impl(const float *dy, int dy_shared, const void *whhT_bf16, const v
     p.dgbuf = (__bf16 *)workspace;
     p.dcbuf = (float *)((char *)workspace + dbytes);
     p.dgates = (__bf16 *)dgates_bf16;
-    zero_async(workspace, dbytes + cbytes, s);
+    {
+        ZeroList zl;
+        zl.add(workspace, dbytes + cbytes);
+        if (persist_enabled())
+            zl.add((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B), (size_t)ctl_bytes(B));
+        zl.launch(s);
+    }
     // whhT_bf16 is [2][H][4H] row-major: rows = hidden unit j, cols = k over 4H
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, s,
                        (const __bf16 *)whhT_bf16, wpack, 2, H, 4 * H, 0);
@@ -1781,7 +1817,6 @@ int lstm_bwd_impl(const float *dy, int dy_shared, const void *whhT_bf16, const v
                            (const __bf16 *)wihT_bf16, wpack + (size_t)2 * H * 4 * H, 2, H, 4 * H, 0);
     if (persist_enabled()) {
         unsigned *ctl_words = (unsigned *)((char *)workspace + asr_lstm_workspace_bytes(B, H) - ctl_bytes(B));
-        zero_async(ctl_words, (size_t)ctl_bytes(B), s);
         void (*pk[3])(LstmBwdParams, LstmTeamCtl) = {nullptr, nullptr, nullptr};
 #define ASR_PICK(KSV) if (H == 16 * KSV && !fused) { pk[0] = lstm_bwd_persist_kernel<KSV, 2>; \
         pk[1] = lstm_bwd_persist_kernel<KSV, 3>; pk[2] = lstm_bwd_persist_kernel<KSV, 4>; }
