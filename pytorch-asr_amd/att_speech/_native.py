@@ -348,6 +348,29 @@ def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True):
     return y, ybf, gates, csave
 
 
+def lens_on(lens, device):
+    """int32 device copy of a CPU length vector.  A host-to-device copy in the middle of a
+    step waits for everything queued before it (pageable memory), after which the small
+    kernels that follow run at the host's launch rate; whoever creates the lengths early in
+    the step (DeepSpeech2.forward) can attach the device copy with `attach_device_lens` and
+    every later consumer picks it up here."""
+    if not isinstance(lens, torch.Tensor):
+        lens = torch.as_tensor(lens)
+    if lens.is_cuda:
+        return lens.to(device=device, dtype=torch.int32)
+    hit = getattr(lens, '_asr_dev', None)
+    if hit is not None and hit[0] == str(device) and hit[1] == lens._version:
+        return hit[2]
+    return lens.to(device=device, dtype=torch.int32)
+
+
+def attach_device_lens(lens, device):
+    """copy a CPU length vector to the device now and remember the copy on the tensor object"""
+    if isinstance(lens, torch.Tensor) and not lens.is_cuda:
+        lens._asr_dev = (str(device), lens._version, lens.to(device=device, dtype=torch.int32))
+    return lens
+
+
 def lstm_dgrad_supported(H):
     return bool(lib().asr_lstm_dgrad_supported(int(H)))
 

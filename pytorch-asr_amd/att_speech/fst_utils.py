@@ -114,9 +114,7 @@ class GraphMatrices(list):
 # ----------------------------------------------------------------------------
 
 def _lens_on(act_lens, device):
-    if not isinstance(act_lens, torch.Tensor):
-        act_lens = torch.as_tensor(act_lens)
-    return act_lens.to(device=device, dtype=torch.int32)
+    return _native.lens_on(act_lens, device)
 
 
 def _assert_sorted(act_lens):

@@ -31,10 +31,20 @@ class SpeechModel(nn.Module):
 
     def forward(self, features, feature_lens, spkids, texts, text_lens,
                 ivectors=None, **kwargs):
+        dec_kwargs = kwargs
+        gg = getattr(self.decoder, 'graph_generator', None)
+        if (features.is_cuda and self.training and texts is not None and 'graph_matrices' not in kwargs
+                and hasattr(gg, 'get_training_graph_device')
+                and hasattr(self.decoder, '_numerator_graphs')):
+            # the numerator lattices are built on the device from the labels; doing it here, at
+            # the start of the step, keeps the labels' host-to-device copy (which waits for the
+            # queue to drain) out of the decoder, where it would sit behind the whole encoder
+            dec_kwargs = dict(kwargs, graph_matrices=gg.get_training_graph_device(
+                texts, text_lens, features.device))
         encoded, encoded_lens = self.encoder(features, feature_lens, spkids,
                                              ivectors, **kwargs)
         return self.decoder(encoded, encoded_lens, texts, text_lens,
-                            spkids=spkids, **kwargs)
+                            spkids=spkids, **dec_kwargs)
 
     def decode(self, features, feature_lens, speakers, texts=None,
                text_lens=None, encoder_args=None, decoder_args=None,

@@ -444,6 +444,8 @@ class FSTDecoder(_ProjectionDecoder):
 
     def _numerator_graphs(self, texts, text_lens, other, device):
         given = other.get('graph_matrices') if other else None
+        if isinstance(given, _native.Graph):      # built on the device at the start of the step
+            return given
         if given is None:
             # built on the device from the labels (the reference builds them on the
             # host at this point, :470-471, or in its data workers)
@@ -461,7 +463,7 @@ class FSTDecoder(_ProjectionDecoder):
         normalisation and stabilisation then run as one pass"""
         gg = self.graph_generator
         numerator = self._numerator_graphs(texts, text_lens, other_data_in_batch, logits.device)
-        lens_dev = torch.as_tensor(encoded_lens).to(logits.device, torch.int32)
+        lens_dev = _native.lens_on(encoded_lens, logits.device)
         if unnormalised:
             shifted, max_sum = _NormaliseShift.apply(logits, lens_dev)   # (:444-452) + (:479-484)
         else:

@@ -171,9 +171,14 @@ class DeepSpeech2(BaseEncoder):
                 characteristic_vectors=None, **kwargs):
         # bs x t x f x c -> bs x c x t x f
         features = features.permute(0, 3, 1, 2)
-        features = self._conv_forward(features)
         features_lengths = torch.as_tensor(features_lengths)
         features_lengths = ((features_lengths + self.conv_cumative_stride - 1)
                             // self.conv_cumative_stride).int()          # (:149-151)
+        if features.is_cuda:
+            # device copy of the lengths now, while the queue is short: the LSTM stack, the
+            # class normalisation and the lattices all take it from here (_native.lens_on)
+            from att_speech import _native
+            _native.attach_device_lens(features_lengths, features.device)
+        features = self._conv_forward(features)
         assert features_lengths[0] == features.size()[0]                 # (:152)
         return self.rnns(features, features_lengths, spkids)

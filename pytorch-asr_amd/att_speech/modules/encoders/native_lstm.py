@@ -204,7 +204,7 @@ class BiLSTMStackFunction(torch.autograd.Function):
 def bilstm_stack(x, lens, rnns):
     """x [T,B,F] GPU tensor through the nn.LSTM modules `rnns` (bidirectional, bias-free,
     one layer each), directions summed after every layer -> [T,B,H] f32."""
-    lens_dev = torch.as_tensor(lens).to(x.device, torch.int32)
+    lens_dev = _native.lens_on(lens, x.device)
     weights = []
     for rnn in rnns:
         weights += [rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.weight_ih_l0_reverse,
@@ -216,7 +216,7 @@ def bilstm(x, lens, rnn, sum_dirs=False):
     """x [T,B,F] GPU tensor, lens [B] (any int tensor), rnn: nn.LSTM(bidirectional,
     bias=False, 1 layer).  Returns per-direction outputs [T,B,2,H], or their sum
     [T,B,H] with sum_dirs."""
-    lens_dev = torch.as_tensor(lens).to(x.device, torch.int32)
+    lens_dev = _native.lens_on(lens, x.device)
     return BiLSTMFunction.apply(
         x.contiguous(), lens_dev, rnn.weight_ih_l0, rnn.weight_hh_l0,
         rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, sum_dirs)
