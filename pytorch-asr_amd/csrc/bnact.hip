@@ -413,11 +413,14 @@ __device__ __forceinline__ void nhwc_block_atomics8(const float (&s)[8], const f
         atomicAdd(&sums[2 * threadIdx.x + 1], (double)b);
     }
 }
+// Work distribution: chunks of 2*PL pixels, grid-strided — the workgroups running at any time
+// then cover one contiguous window of the tensor.  With one private contiguous slice per
+// workgroup (as in the 4-channel kernels above) 2048 concurrent workgroups stream 2048
+// regions 76 KB apart and the bf16 passes ran at 2.4 TB/s of read + write.
 #define NHWC8_THREAD_SETUP(P_)                                                         \
     const int CG = C / 8, PL = 256 / CG, c0 = 8 * ((int)threadIdx.x % CG),             \
               pl = (int)threadIdx.x / CG;                                              \
-    const int64_t per = ((P_) + gridDim.x - 1) / gridDim.x;                            \
-    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < (P_) ? p0 + per : (P_)
+    const int64_t pend = (P_), cstep = (int64_t)gridDim.x * 2 * PL
 
 template <typename XT, typename OutT>
 __global__ __launch_bounds__(256) void bn_act_fwd_nhwc8_kernel(BnParamsN p, OutT *out) {
@@ -436,13 +439,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_nhwc8_kernel(BnParamsN p, OutT
         for (int i = 0; i < 8; ++i) y.v[i] = fminf(fmaxf(fmaf(v.v[i], sc[i], sh[i]), p.lo), p.hi);
         store8(out + pix * C + c0, y);
     };
-    int64_t pix = p0 + pl;
-    for (; pix + PL < p1; pix += 2 * PL) {
-        const F8 v0 = load8(px + pix * C + c0), v1 = load8(px + (pix + PL) * C + c0);
-        one(pix, v0);
-        one(pix + PL, v1);
+    for (int64_t pix = (int64_t)blockIdx.x * 2 * PL + pl; pix < pend; pix += cstep) {
+        if (pix + PL < pend) {
+            const F8 v0 = load8(px + pix * C + c0), v1 = load8(px + (pix + PL) * C + c0);
+            one(pix, v0);
+            one(pix + PL, v1);
+        } else {
+            one(pix, load8(px + pix * C + c0));
+        }
     }
-    for (; pix < p1; pix += PL) one(pix, load8(px + pix * C + c0));
 }
 
 // MODE 0: sums[c] = { sum dyh, sum dyh * xhat };  MODE 1: dx
@@ -473,14 +478,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_nhwc8_kernel(BnParamsN p, cons
         }
         if (MODE == 1) store8(dx + pix * C + c0, o);
     };
-    int64_t pix = p0 + pl;
-    for (; pix + PL < p1; pix += 2 * PL) {        // two pixels per trip: four loads in flight
-        const F8 v0 = load8(px + pix * C + c0), v1 = load8(px + (pix + PL) * C + c0);
-        const F8 d0 = load8(dy + pix * C + c0), d1 = load8(dy + (pix + PL) * C + c0);
-        one(pix, v0, d0);
-        one(pix + PL, v1, d1);
+    for (int64_t pix = (int64_t)blockIdx.x * 2 * PL + pl; pix < pend; pix += cstep) {
+        if (pix + PL < pend) {                    // two pixels per trip: four loads in flight
+            const F8 v0 = load8(px + pix * C + c0), v1 = load8(px + (pix + PL) * C + c0);
+            const F8 d0 = load8(dy + pix * C + c0), d1 = load8(dy + (pix + PL) * C + c0);
+            one(pix, v0, d0);
+            one(pix + PL, v1, d1);
+        } else {
+            one(pix, load8(px + pix * C + c0), load8(dy + pix * C + c0));
+        }
     }
-    for (; pix < p1; pix += PL) one(pix, load8(px + pix * C + c0), load8(dy + pix * C + c0));
     if (MODE == 0) nhwc_block_atomics8(s, q, C, sums);
 }
 
