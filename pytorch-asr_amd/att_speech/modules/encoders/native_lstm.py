@@ -23,11 +23,13 @@ def _mm_f32(a, b):
 
 
 def _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, want_y):
-    """One layer's recurrence from its bf16 input [T*B, F].  With F == H the input
-    projection runs inside the persistent kernel (asr_lstm_bidir_fwd_fused_bf16: no
-    [T*B, 8H] product in HBM; ASR_LSTM_FUSED=0 restores the GEMM); otherwise x·W_ih is one
-    GEMM, accumulated in fp32 and stored once as bf16 (ASR_GX_FP32=1 keeps fp32: the
-    product is 1.75 GB in fp32 at B=512 and its write bounds the GEMM)."""
+    """One layer's recurrence from its bf16 input [T*B, F].  Where the library has the fused
+    kernel (F == H; or H = 320, F = 352 when the fp32 outputs are not wanted) the input
+    projection runs inside the persistent recurrence (asr_lstm_bidir_fwd_fused_bf16: no
+    [T*B, 8H] product in HBM; ASR_LSTM_FUSED=0 restores the GEMM everywhere, =inner for the
+    F != H layer only); otherwise x·W_ih is one GEMM, accumulated in fp32 and stored once as
+    bf16 (ASR_GX_FP32=1 keeps fp32: the product is 1.75 GB in fp32 at B=512 and its write
+    bounds the GEMM)."""
     F = xb.shape[1]
     mode = os.environ.get('ASR_LSTM_FUSED', '1')         # 0: never, inner: only F == H layers
     if (mode != '0' and (F == H or (not want_y and mode != 'inner'))
@@ -47,6 +49,9 @@ def _input_gradient(dgb, w_ih, T, B, H, F, bf16_out=False):
     if (not bf16_out and F == H and os.environ.get('ASR_LSTM_DGRAD', '1') != '0'
             and _native.lstm_dgrad_supported(H) and T * B * 16 * H < 2 ** 31 - 2 ** 20):
         return _native.lstm_dgrad(dgb.view(T, B, 2, 4 * H), w_ih)
+    # K-major second operand: the library's kernel for it is faster here (probe 0.38 vs
+    # 0.44 ms) than the one it picks for the row-major [8H, F] weight; the transpose is
+    # a 1.6 MB copy
     wk = w_ih.t().contiguous().t()
     dg2 = dgb.view(T * B, 8 * H)
     return (torch.mm(dg2, wk) if bf16_out else _mm_f32(dg2, wk)).view(T, B, F)
@@ -92,10 +97,6 @@ class BiLSTMFunction(torch.autograd.Function):
         F = xb.shape[1]
         whhT = whh.transpose(1, 2).contiguous()                          # [2,H,4H]
         dgb = _native.lstm_bidir_bwd(dy.contiguous(), whhT, lens_dev, gates, csave)
-        dg2 = dgb.view(T * B, 2 * 4 * H)                                 # bf16
-        # K-major second operand: the library's kernel for it is faster here (probe 0.38 vs
-        # 0.44 ms) than the one it picks for the row-major [8H, F] weight; the transpose is
-        # a 1.6 MB copy
         dx = _input_gradient(dgb, w_ih, T, B, H, F, bf16_out=ctx.x_bf16)
         # Weight gradients: [4H.. x TB] x [TB x F|H] with TB = T*B frames and a small
         # output.  As one GEMM the library fills 100-170 of 256 CUs (0.79 / 1.06 ms
@@ -113,7 +114,7 @@ def _weight_gradients(dgb, xb, ybf, T, B, H, F):
     asr_lstm_wgrad_bf16 where it is built (H = 320; ASR_LSTM_WGRAD=0 switches it off), the
     chunked library products otherwise — and for dW_ih of a layer whose input size is not H."""
     if os.environ.get('ASR_LSTM_WGRAD', '1') != '0' and _native.lstm_wgrad_supported(H) \
-            and T * B * 16 * H < 2 ** 31:
+            and (T * B + 1024) * 16 * H < 2 ** 31:        # the kernel's 32-bit buffer offsets
         if F == H:
             dw_ih, dw_hh = _native.lstm_wgrad(dgb.view(T, B, 2, 4 * H), xb, ybf)
             return dw_ih, [dw_hh[0], dw_hh[1]]

@@ -1496,12 +1496,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_dx_kernel(LstmBwdParams p, LstmT
 #endif
 }
 
-__global__ void zero_bytes_kernel(uint32_t *p, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) p[i] = 0u;
-}
-
 // several ranges in ONE launch (a forward call clears its state buffers, the four pad frames
 // of y_bf16 and the team counters: six 5-us launches per layer and direction pair otherwise)
 struct ZeroRanges { uint32_t *p[6]; size_t n[6]; int count; };
@@ -1528,14 +1522,6 @@ struct ZeroList {
         hipLaunchKernelGGL(zero_ranges_kernel, dim3(blocks), dim3(256), 0, s, z);
     }
 };
-
-inline void zero_async(void *p, size_t bytes, hipStream_t s) {
-    const size_t n = bytes / 4;
-    if (!n) return;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(zero_bytes_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t *)p, n);
-}
 
 inline int64_t ctl_bytes(int B) { return ((int64_t)2 * ((B + 15) / 16) * 128 + 256 + 255) / 256 * 256; }
 
