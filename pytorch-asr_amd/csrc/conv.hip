@@ -26,6 +26,31 @@ constexpr int KS = 7;             // kernel size (both axes)
 constexpr int PIX = 80;           // bytes per pixel in LDS
 constexpr int KSTEPS = KS * KS * CH / 16;      // 98 MFMA k-steps of 16
 
+// LDS-DMA: 64 lanes x 16 bytes from a bounds-checked raw buffer straight to LDS at
+// `lds_byte` + 16 * lane (out-of-range lanes write zeros); inline asm because hipcc orders
+// every LDS read behind an LDS-DMA it knows of with s_waitcnt vmcnt(0)
+typedef __attribute__((ext_vector_type(4))) int rsrc_words;
+__device__ __forceinline__ rsrc_words conv_raw_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    rsrc_words r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void conv_dma16(rsrc_words r, unsigned lds_byte, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_byte), "v"(voff), "s"(r), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned conv_lds_addr(const void *ptr) {
+    return (unsigned)(size_t)((__attribute__((address_space(3))) const void *)ptr);
+}
+
 // LDS row pitch (bytes) of a staged image whose MFMA tiles take 32 consecutive pixels of rows
 // `per_row` pixels long, `step` image rows apart: the pitch >= min_pitch (multiple of 16, at
 // most 256 bytes more) with the fewest ds_read_b128 bank conflicts over the first `ntiles`
@@ -61,6 +86,13 @@ inline int pick_row_pitch(int min_pitch, int per_row, int step, int npix, int nt
         if (cost < best_cost) { best_cost = cost; best = P; }
     }
     return best;
+}
+
+inline int conv_cu_count() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
 }
 
 // ---- per-channel statistics of an output image in LDS -------------------------------------
@@ -119,24 +151,45 @@ struct ConvFwdParams {
     const __bf16 *wpack;
     __bf16 *y;
     float *stats;                 // [workgroups][64] channel sums of the outputs, or null
-    int B, H, W, Ho, Wo, R;       // R output rows per workgroup (R * Wo <= 192)
+    int B, H, W, Ho, Wo, R;       // R output rows per workgroup (R * Wo <= FWD_PIX)
     int pitch;                    // bytes per image row in LDS (pick_row_pitch)
 };
 
-// one k-half (49 k-steps) of the product for 3 M-tiles
+// M-tiles per wave of the forward kernel.  Three (192 pixels per workgroup) left no register
+// for a second A fragment next to the 49 weight fragments and 48 accumulators: every MFMA
+// waited for the LDS read issued right in front of it (ds_read -> s_waitcnt lgkmcnt(0) ->
+// v_mfma, 147 times: MFMA-busy 19 %).  With two, three fragments are in flight.
+constexpr int FWD_NT = 2, FWD_PIX = 2 * FWD_NT * 32, FWD_AD = 3;
+
+// one k-half (49 k-steps) of the product for FWD_NT M-tiles: the A fragments are read FWD_AD
+// MFMAs ahead into a rotating register set, the order pinned (sched_group_barrier: the
+// scheduler otherwise sinks every read next to its use again)
 template <int SH, int KH>
-__device__ __forceinline__ void conv_fwd_half(const char *img, const unsigned (&pixbase)[3], int pitch,
-                                              const bf16x8 (&bf)[49], f32x16 (&acc)[3]) {
-#pragma unroll
-    for (int s = 0; s < 49; ++s) {
+__device__ __forceinline__ void conv_fwd_half(const char *img, const unsigned (&pixbase)[FWD_NT], int pitch,
+                                              const bf16x8 (&bf)[49], f32x16 (&acc)[FWD_NT]) {
+    constexpr int N = 49 * FWD_NT;
+    auto frag = [&](int idx) {
+        const int s = idx / FWD_NT, i = idx % FWD_NT;
         const int ks = 49 * KH + s;
         const int kt = ks / 14, rem = ks % 14, kf = rem >> 1, cp = rem & 1;
         const unsigned off = (unsigned)(kt * pitch + kf * PIX + cp * 32);
+        return *reinterpret_cast<const bf16x8 *>(img + pixbase[i] + off);
+    };
+    bf16x8 a[FWD_AD];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(img + pixbase[i] + off);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[s], acc[i], 0, 0, 0);
-        }
+    for (int d = 0; d < FWD_AD; ++d) a[d] = frag(d);
+#pragma unroll
+    for (int idx = 0; idx < N; ++idx) {
+        acc[idx % FWD_NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[idx % FWD_AD], bf[idx / FWD_NT],
+                                                                    acc[idx % FWD_NT], 0, 0, 0);
+        if (idx + FWD_AD < N) a[idx % FWD_AD] = frag(idx + FWD_AD);
+    }
+#pragma unroll
+    for (int d = 0; d < FWD_AD; ++d) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int idx = 0; idx < N; ++idx) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (idx + FWD_AD < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 }
 
@@ -146,45 +199,59 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave & 1, mh = wave >> 1;
-    const int b = blockIdx.y, ho0 = blockIdx.x * p.R;
     const int W = p.W, Wo = p.Wo, R = p.R;
     const int in_rows = SH * (R - 1) + KS;
-    const int h0 = ho0 * SH;
 
-    // ---- weight fragments of this wave's k-half ------------------------------------------
+    // ---- weight fragments of this wave's k-half: loaded ONCE per workgroup.  The grid is
+    // persistent (two workgroups per CU, each walking the (utterance, row block) items): with
+    // one item per workgroup every workgroup re-read its 196 KB of fragments from L2 — 3.5 GB
+    // per call against 0.6 GB of input, and at the ~25 B/clk a CU takes in that, not the MFMA
+    // loop, set the pace (469 us with or without the pipelined loop above).
     bf16x8 bf[49];
     {
         const bf16x8 *src = reinterpret_cast<const bf16x8 *>(p.wpack) + (size_t)(49 * kh) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < 49; ++s) bf[s] = src[(size_t)s * 64];
     }
-    // ---- stage the input rows ----------------------------------------------------------------
+    const rsrc_words xR = conv_raw_rsrc(p.x, (unsigned)((size_t)p.B * p.H * W * 64));
+    const int tiles = (p.Ho + R - 1) / R, nitems = tiles * p.B;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / tiles, ho0 = (item - b * tiles) * R;
+    const int h0 = ho0 * SH;
+    __syncthreads();                                            // the previous item's epilogue is done with LDS
+    // ---- stage the input rows: global -> LDS by LDS-DMA, 1 KiB of the padded image per
+    // instruction (with 196 weight registers there is none to stage through, and a load ->
+    // LDS-store loop one chunk at a time cost 20k cycles per item).  The image is linear in
+    // LDS — rows `pitch` bytes apart, pixels 80 bytes apart — so each lane works out which
+    // (row, pixel, 16-byte part) its slot belongs to; slots in the padding, past the image
+    // row or past the tensor read out of range and write zeros.
     {
-        const int chunks = in_rows * W * 4;                     // 16-byte chunks
-        const char *xb = reinterpret_cast<const char *>(p.x) + (size_t)b * p.H * W * 64;
-        for (int c = tid; c < chunks; c += 256) {
-            const int pix = c >> 2, part = c & 3;
-            const int row = pix / W;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (h0 + row < p.H)
-                v = *reinterpret_cast<const u32x4 *>(xb + ((size_t)(h0 + row) * W * 64 + (size_t)(pix - row * W) * 64 + part * 16));
-            *reinterpret_cast<u32x4 *>(smem + row * p.pitch + (pix - row * W) * PIX + part * 16) = v;
+        const unsigned img_bytes = (unsigned)in_rows * (unsigned)p.pitch;
+        const unsigned soff = (unsigned)b * (unsigned)(p.H * W * 64);
+        for (unsigned q = (unsigned)wave; q * 1024u < img_bytes; q += 4) {
+            const unsigned beta = q * 1024u + (unsigned)lane * 16u;
+            const unsigned row = beta / (unsigned)p.pitch, rem = beta - row * (unsigned)p.pitch;
+            const unsigned pix = (rem * 52429u) >> 22, within = rem - pix * 80u;       // rem / 80 for rem < 2^16
+            const bool ok = beta < img_bytes && pix < (unsigned)W && within < 64u && h0 + (int)row < p.H;
+            const unsigned voff = ok ? ((unsigned)(h0 + (int)row) * (unsigned)W + pix) * 64u + within : 0x80000000u;
+            conv_dma16(xR, (unsigned)__builtin_amdgcn_readfirstlane((int)(conv_lds_addr(smem) + q * 1024u)), voff, soff);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // ---- per-lane pixel bases of this wave's three M-tiles -------------------------------------
-    unsigned pixbase[3];
+    // ---- per-lane pixel bases of this wave's M-tiles -------------------------------------------
+    unsigned pixbase[FWD_NT];
     const int npix = R * Wo;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        int m = 32 * (3 * mh + i) + (lane & 31);
+    for (int i = 0; i < FWD_NT; ++i) {
+        int m = 32 * (FWD_NT * mh + i) + (lane & 31);
         if (m >= npix) m = npix - 1;                            // computed, never stored
         const int r = m / Wo, wo = m - r * Wo;
         pixbase[i] = (unsigned)((r * SH) * p.pitch + wo * PIX + (lane >> 5) * 16);
     }
     __syncthreads();
-    f32x16 acc[3];
+    f32x16 acc[FWD_NT];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < FWD_NT; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     if (kh == 0) conv_fwd_half<SH, 0>(smem, pixbase, p.pitch, bf, acc);
@@ -192,22 +259,22 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
     __syncthreads();                                            // image no longer needed
 
     // ---- sum the two k-halves, convert, write [pixel][co] rows to LDS, copy out coalesced -----
-    float *part = reinterpret_cast<float *>(smem);              // [2 mh][3][16][64] fp32 = 24 KB
-    __bf16 *oimg = reinterpret_cast<__bf16 *>(smem + 2 * 3 * 16 * 64 * 4);   // [192][32] bf16
+    float *part = reinterpret_cast<float *>(smem);              // [2 mh][FWD_NT][16][64] fp32
+    __bf16 *oimg = reinterpret_cast<__bf16 *>(smem + 2 * FWD_NT * 16 * 64 * 4);   // [FWD_PIX][32] bf16
     if (kh == 1) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < FWD_NT; ++i)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) part[((mh * 3 + i) * 16 + j) * 64 + lane] = acc[i][j];
+            for (int j = 0; j < 16; ++j) part[((mh * FWD_NT + i) * 16 + j) * 64 + lane] = acc[i][j];
     }
     __syncthreads();
     if (kh == 0) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < FWD_NT; ++i)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float v = acc[i][j] + part[((mh * 3 + i) * 16 + j) * 64 + lane];
-                const int m = 32 * (3 * mh + i) + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+                const float v = acc[i][j] + part[((mh * FWD_NT + i) * 16 + j) * 64 + lane];
+                const int m = 32 * (FWD_NT * mh + i) + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
                 oimg[m * CH + (lane & 31)] = (__bf16)v;
             }
     }
@@ -221,7 +288,8 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
                 *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(oimg) + (size_t)c * 16);
     }
     if (p.stats)        // `part` (the k-half exchange) is free again: scratch
-        chan_partial_sums(oimg, rows_here * Wo, part, p.stats + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64);
+        chan_partial_sums(oimg, rows_here * Wo, part, p.stats + (size_t)item * 64);
+    }
 }
 
 
@@ -699,11 +767,13 @@ extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int
     if (stride_h != 1 && stride_h != 3) return ASR_EUNSUPPORTED;
     const int Ho = (H - KS) / stride_h + 1, Wo = W - KS + 1;
     if (Wo > 48) return ASR_EUNSUPPORTED;
-    int R = 192 / Wo;
+    int R = FWD_PIX / Wo;
     if (R > 16) R = 16;
-    const int pitch = pick_row_pitch(W * PIX, Wo, stride_h, R * Wo, 6);
-    const size_t img = (size_t)(stride_h * (R - 1) + KS) * pitch;
-    const size_t epi = (size_t)2 * 3 * 16 * 64 * 4 + (size_t)192 * CH * 2;
+    const int pitch = pick_row_pitch(W * PIX, Wo, stride_h, R * Wo, 2 * FWD_NT);
+    // (the image is filled in whole 1 KiB DMA blocks)
+    const size_t img = ((size_t)(stride_h * (R - 1) + KS) * pitch + 1023) / 1024 * 1024;
+    if ((int64_t)B * H * W * 64 >= (1ll << 31)) return ASR_EUNSUPPORTED;       // 32-bit buffer offsets
+    const size_t epi = (size_t)2 * FWD_NT * 16 * 64 * 4 + (size_t)FWD_PIX * CH * 2 + 2048;
     const size_t lds = img > epi ? img : epi;
     if (lds > 80 * 1024) return ASR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -712,10 +782,14 @@ extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int
     ConvFwdParams p;
     p.x = (const __bf16 *)x; p.wpack = wpack; p.y = (__bf16 *)y;
     p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.R = R; p.pitch = pitch;
-    const dim3 grid((Ho + R - 1) / R, B);
+    const int nitems = ((Ho + R - 1) / R) * B;
+    int wgs = 2 * conv_cu_count();
+    if (wgs <= 0) wgs = 512;
+    if (wgs > nitems) wgs = nitems;
+    const dim3 grid(wgs);
     // the weight gradient's partial-sum area doubles as the statistics' (never live together)
     p.stats = chan_sums ? (float *)((char *)workspace + (size_t)KSTEPS * 64 * 8 * 2 * 2) : nullptr;
-    if (chan_sums && (int64_t)grid.x * grid.y * 64 * 4 > (int64_t)WGRAD_WGS * 49 * 1024 * 4) return ASR_EUNSUPPORTED;
+    if (chan_sums && (int64_t)nitems * 64 * 4 > (int64_t)WGRAD_WGS * 49 * 1024 * 4) return ASR_EUNSUPPORTED;
     void (*kern)(ConvFwdParams) = stride_h == 3 ? conv7x7c32_fwd_kernel<3> : conv7x7c32_fwd_kernel<1>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -723,7 +797,7 @@ extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     if (chan_sums) {
         hipLaunchKernelGGL(zero_chan_sums_kernel, dim3(1), dim3(64), 0, s, chan_sums);
-        hipLaunchKernelGGL(chan_sums_reduce_kernel, dim3(64), dim3(1024), 0, s, p.stats, (int)(grid.x * grid.y), chan_sums);
+        hipLaunchKernelGGL(chan_sums_reduce_kernel, dim3(64), dim3(1024), 0, s, p.stats, nitems, chan_sums);
     }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
