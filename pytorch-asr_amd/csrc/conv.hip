@@ -20,6 +20,8 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 constexpr int CH = 32;            // channels in and out
 constexpr int KS = 7;             // kernel size (both axes)
@@ -320,20 +322,40 @@ struct ConvDgradParams {
     int pitch;                    // bytes per (padded) dy row in LDS (pick_row_pitch)
 };
 
-// NS k-steps starting at class-local step S0 (class row count J = 3 for r = 0, else 2)
+// M-tiles (32 pixels each) per wave and class of the input-gradient kernel, and how many A
+// fragments are read ahead of their MFMA
+constexpr int DG_NT = 6, DG_PIX = DG_NT * 32, DG_AD = 2;
+
+// NS k-steps starting at class-local step S0 (class row count J = 3 for r = 0, else 2).
+// The operands are SWAPPED (weights as the MFMA's A, dy pixels as its B): the product comes out
+// transposed, each lane holding 4 consecutive ci of one pixel per register quad — 8-byte LDS
+// writes in the epilogue instead of 2-byte ones.  Reads run DG_AD MFMAs ahead, order pinned.
 template <int NS, int S0>
-__device__ __forceinline__ void conv_dgrad_part(const char *img, const unsigned (&pixbase)[6], int pitch,
-                                                const bf16x8 *bf, f32x16 (&acc)[6]) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
+__device__ __forceinline__ void conv_dgrad_part(const char *img, const unsigned (&pixbase)[DG_NT], int pitch,
+                                                const bf16x8 (&bf)[28], f32x16 (&acc)[DG_NT]) {
+    constexpr int N = NS * DG_NT;
+    auto frag = [&](int idx) {
+        const int s = idx / DG_NT, i = idx % DG_NT;
         const int sl = S0 + s;
         const int j = sl / 14, rem = sl % 14, kf = rem >> 1, cp = rem & 1;
         const unsigned off = (unsigned)((2 - j) * pitch + (6 - kf) * PIX + cp * 32);
+        return *reinterpret_cast<const bf16x8 *>(img + pixbase[i] + off);
+    };
+    bf16x8 a[DG_AD];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(img + pixbase[i] + off);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[s], acc[i], 0, 0, 0);
-        }
+    for (int d = 0; d < DG_AD; ++d) a[d] = frag(d);
+#pragma unroll
+    for (int idx = 0; idx < N; ++idx) {
+        acc[idx % DG_NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[idx / DG_NT], a[idx % DG_AD],
+                                                                   acc[idx % DG_NT], 0, 0, 0);
+        if (idx + DG_AD < N) a[idx % DG_AD] = frag(idx + DG_AD);
+    }
+#pragma unroll
+    for (int d = 0; d < DG_AD; ++d) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int idx = 0; idx < N; ++idx) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (idx + DG_AD < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 }
 
@@ -341,10 +363,11 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradPa
     extern __shared__ char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, q0 = blockIdx.x * p.Rq;
-    const int W = p.W, Wo = p.Wo, Rq = p.Rq, Wp = Wo + 12;
+    const int W = p.W, Wo = p.Wo, Rq = p.Rq;
     // wave 0: class 0, k-steps 0..20; wave 1: class 0, 21..41; wave 2: class 1; wave 3: class 2
     const int r = wave < 2 ? 0 : wave - 1;
+    // ---- this wave's weight fragments: loaded ONCE per workgroup (persistent grid, as in the
+    // forward kernel: one item per workgroup re-read 100 KB of fragments for 9 KB of dy) --------
     bf16x8 bf[28];
     {
         const int first = wave == 0 ? 0 : (wave == 1 ? 21 : (wave == 2 ? 42 : 70));
@@ -353,34 +376,41 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradPa
 #pragma unroll
         for (int s = 0; s < 28; ++s) bf[s] = s < n ? src[(size_t)s * 64] : bf16x8{};
     }
-    // ---- stage dy rows q0-2 .. q0+Rq-1, zero-padded by 6 pixels on both sides -------------------
-    {
-        const int rows = Rq + 2;
-        const int chunks = rows * Wp * 4;
-        const char *yb = reinterpret_cast<const char *>(p.dy) + (size_t)b * p.Ho * Wo * 64;
-        for (int c = tid; c < chunks; c += 256) {
-            const int pix = c >> 2, part = c & 3;
-            const int row = pix / Wp, col = pix - row * Wp;
-            const int ho = q0 - 2 + row, wo = col - 6;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ho >= 0 && ho < p.Ho && wo >= 0 && wo < Wo)
-                v = *reinterpret_cast<const u32x4 *>(yb + ((size_t)ho * Wo + wo) * 64 + part * 16);
-            *reinterpret_cast<u32x4 *>(smem + row * p.pitch + col * PIX + part * 16) = v;
-        }
-    }
-    unsigned pixbase[6];
+    const rsrc_words yR = conv_raw_rsrc(p.dy, (unsigned)((size_t)p.B * p.Ho * Wo * 64));
+    unsigned pixbase[DG_NT];
     const int npix = Rq * W;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < DG_NT; ++i) {
         int m = 32 * i + (lane & 31);
         if (m >= npix) m = npix - 1;
         const int q = m / W, w = m - q * W;
         pixbase[i] = (unsigned)(q * p.pitch + w * PIX + (lane >> 5) * 16);
     }
+    const int nq = (p.H + 2) / 3;                               // q = 0 .. ceil(H / 3) - 1
+    const int tiles = (nq + Rq - 1) / Rq, nitems = tiles * p.B;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / tiles, q0 = (item - b * tiles) * Rq;
+    __syncthreads();                                            // the previous item's epilogue is done with LDS
+    // ---- stage dy rows q0-2 .. q0+Rq-1, zero-padded by 6 pixels on both sides: LDS-DMA, 1 KiB
+    // of the linear LDS image per instruction; padding slots read out of range = zeros ----------
+    {
+        const unsigned img_bytes = (unsigned)(Rq + 2) * (unsigned)p.pitch;
+        const unsigned soff = (unsigned)b * (unsigned)(p.Ho * Wo * 64);
+        for (unsigned qd = (unsigned)wave; qd * 1024u < img_bytes; qd += 4) {
+            const unsigned beta = qd * 1024u + (unsigned)lane * 16u;
+            const unsigned row = beta / (unsigned)p.pitch, rem = beta - row * (unsigned)p.pitch;
+            const unsigned col = (rem * 52429u) >> 22, within = rem - col * 80u;        // rem / 80 for rem < 2^16
+            const int ho = q0 - 2 + (int)row, wo = (int)col - 6;
+            const bool ok = beta < img_bytes && within < 64u && ho >= 0 && ho < p.Ho && wo >= 0 && wo < Wo;
+            const unsigned voff = ok ? ((unsigned)ho * (unsigned)Wo + (unsigned)wo) * 64u + within : 0x80000000u;
+            conv_dma16(yR, (unsigned)__builtin_amdgcn_readfirstlane((int)(conv_lds_addr(smem) + qd * 1024u)), voff, soff);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    f32x16 acc[6];
+    f32x16 acc[DG_NT];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < DG_NT; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     if (wave == 0) conv_dgrad_part<21, 0>(smem, pixbase, p.pitch, bf, acc);
@@ -388,25 +418,32 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradPa
     else conv_dgrad_part<28, 0>(smem, pixbase, p.pitch, bf, acc);
     __syncthreads();
 
-    // ---- epilogue: wave 1 -> wave 0 partial sum; [class][pixel][ci] bf16 image; coalesced rows ----
-    float *part = reinterpret_cast<float *>(smem);              // [6][16][64] fp32 = 24 KB
-    __bf16 *oimg = reinterpret_cast<__bf16 *>(smem + 6 * 16 * 64 * 4);       // [3][192][32] bf16
+    // ---- epilogue: wave 1 -> wave 0 partial sum; [class][pixel][ci] bf16 image (the 16-byte
+    // chunks of a pixel XORed with (pixel >> 2) & 3: the 32 pixels of an 8-byte write otherwise
+    // sit on 4 bank groups); coalesced rows out --------------------------------------------------
+    f32x4 *part = reinterpret_cast<f32x4 *>(smem);              // [DG_NT][4][64] x 16 B = 24 KB
+    char *oimg = smem + DG_NT * 4 * 64 * 16;                    // [3][DG_PIX][32] bf16
     if (wave == 1) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < DG_NT; ++i)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) part[(i * 16 + j) * 64 + lane] = acc[i][j];
+            for (int g = 0; g < 4; ++g)
+                part[(i * 4 + g) * 64 + lane] = f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
     }
     __syncthreads();
     if (wave != 1) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < DG_NT; ++i)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                float v = acc[i][j];
-                if (wave == 0) v += part[(i * 16 + j) * 64 + lane];
-                const int m = 32 * i + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
-                oimg[(r * 192 + m) * CH + (lane & 31)] = (__bf16)v;
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+                if (wave == 0) {
+                    const f32x4 o = part[(i * 4 + g) * 64 + lane];
+                    v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                }
+                const int m = 32 * i + (lane & 31);
+                bf16x4 o4 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4 *>(oimg + (r * DG_PIX + m) * 64 + ((g ^ ((m >> 2) & 3)) << 4) + ((lane >> 5) << 3)) = o4;
             }
     }
     __syncthreads();
@@ -419,11 +456,12 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradPa
             const int rowi = c / chunks_per_row, within = c - rowi * chunks_per_row;
             const int rc = rowi / Rq, q = rowi - rc * Rq;
             const int h = 3 * (q0 + q) + rc;
+            const int m = q * W + (within >> 2), k = within & 3;
             if (h < p.H)
                 *reinterpret_cast<u32x4 *>(xb + (size_t)h * W * 64 + (size_t)within * 16) =
-                    *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(oimg) +
-                                                     ((size_t)(rc * 192 + q * W) * 64 + (size_t)within * 16));
+                    *reinterpret_cast<const u32x4 *>(oimg + (rc * DG_PIX + m) * 64 + ((k ^ ((m >> 2) & 3)) << 4));
         }
+    }
     }
 }
 
@@ -811,11 +849,13 @@ extern "C" int asr_conv7x7c32_bwd_data_bf16(const void *dy, const float *w, int 
     if (stride_h != 3) return ASR_EUNSUPPORTED;
     const int Ho = (H - KS) / stride_h + 1, Wo = W - KS + 1;
     if (W > 48) return ASR_EUNSUPPORTED;
-    int Rq = 192 / W;
+    int Rq = DG_PIX / W;
     if (Rq > 16) Rq = 16;
-    const int pitch = pick_row_pitch((Wo + 12) * PIX, W, 1, Rq * W, 6);
-    const size_t img = (size_t)(Rq + 2) * pitch;
-    const size_t epi = (size_t)6 * 16 * 64 * 4 + (size_t)3 * 192 * CH * 2;
+    const int pitch = pick_row_pitch((Wo + 12) * PIX, W, 1, Rq * W, DG_NT);
+    // (the image is filled in whole 1 KiB DMA blocks)
+    const size_t img = ((size_t)(Rq + 2) * pitch + 1023) / 1024 * 1024;
+    if ((int64_t)B * Ho * Wo * 64 >= (1ll << 31)) return ASR_EUNSUPPORTED;     // 32-bit buffer offsets
+    const size_t epi = (size_t)DG_NT * 4 * 64 * 16 + (size_t)3 * DG_PIX * CH * 2;
     const size_t lds = img > epi ? img : epi;
     if (lds > 80 * 1024) return ASR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -825,7 +865,11 @@ extern "C" int asr_conv7x7c32_bwd_data_bf16(const void *dy, const float *w, int 
     p.dy = (const __bf16 *)dy; p.wpack = wpack; p.dx = (__bf16 *)dx;
     p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Rq = Rq; p.pitch = pitch;
     const int nq = (H + 2) / 3;                                  // q = 0 .. ceil(H / 3) - 1
-    const dim3 grid((nq + Rq - 1) / Rq, B);
+    const int nitems = ((nq + Rq - 1) / Rq) * B;
+    int wgs = 2 * conv_cu_count();
+    if (wgs <= 0) wgs = 512;
+    if (wgs > nitems) wgs = nitems;
+    const dim3 grid(wgs);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)conv7x7c32_dgrad_s3_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
