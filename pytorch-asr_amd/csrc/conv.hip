@@ -12,6 +12,7 @@
 // consecutive pixels hit 16 disjoint bank groups), keeps its share of the weight fragments in
 // REGISTERS for its whole life, and feeds v_mfma_f32_32x32x16_bf16 with one ds_read_b128 per
 // MFMA whose address is a per-lane pixel base + an immediate (tap) offset.
+#include <type_traits>
 #include "common.h"
 #include "../../include/asr_amd.h"
 
@@ -148,7 +149,16 @@ __global__ void conv_pack_fwd_kernel(const float *w, __bf16 *out) {
     out[i] = (__bf16)w[((co * CH + ci) * KS + kt) * KS + kf];
 }
 
+// Diagnostic build only (-DCONV_STAMPS, ASR_CONV_STAMPS=1): per-phase s_memtime stamps of one
+// workgroup's item loop, printed by the host entry points
+#ifdef CONV_STAMPS
+#define STAMP(k) do { if (p.stamps && blockIdx.x == 7 && lane == 0 && nst < 64) { p.stamps[(wave * 64 + nst) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 struct ConvFwdParams {
+    long long *stamps;
     const __bf16 *x;
     const __bf16 *wpack;
     __bf16 *y;
@@ -217,10 +227,12 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
     }
     const rsrc_words xR = conv_raw_rsrc(p.x, (unsigned)((size_t)p.B * p.H * W * 64));
     const int tiles = (p.Ho + R - 1) / R, nitems = tiles * p.B;
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    int nst = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++nst) {
     const int b = item / tiles, ho0 = (item - b * tiles) * R;
     const int h0 = ho0 * SH;
     __syncthreads();                                            // the previous item's epilogue is done with LDS
+    STAMP(0);
     // ---- stage the input rows: global -> LDS by LDS-DMA, 1 KiB of the padded image per
     // instruction (with 196 weight registers there is none to stage through, and a load ->
     // LDS-store loop one chunk at a time cost 20k cycles per item).  The image is linear in
@@ -240,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    STAMP(1);
     // ---- per-lane pixel bases of this wave's M-tiles -------------------------------------------
     unsigned pixbase[FWD_NT];
     const int npix = R * Wo;
@@ -251,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
         pixbase[i] = (unsigned)((r * SH) * p.pitch + wo * PIX + (lane >> 5) * 16);
     }
     __syncthreads();
+    STAMP(2);
     f32x16 acc[FWD_NT];
 #pragma unroll
     for (int i = 0; i < FWD_NT; ++i)
@@ -258,7 +272,9 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     if (kh == 0) conv_fwd_half<SH, 0>(smem, pixbase, p.pitch, bf, acc);
     else conv_fwd_half<SH, 1>(smem, pixbase, p.pitch, bf, acc);
+    STAMP(3);
     __syncthreads();                                            // image no longer needed
+    STAMP(4);
 
     // ---- sum the two k-halves, convert, write [pixel][co] rows to LDS, copy out coalesced -----
     float *part = reinterpret_cast<float *>(smem);              // [2 mh][FWD_NT][16][64] fp32
@@ -281,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
             }
     }
     __syncthreads();
+    STAMP(5);
     const int rows_here = (p.Ho - ho0) < R ? (p.Ho - ho0) : R;
     {
         const int chunks = rows_here * Wo * 4;
@@ -291,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
     }
     if (p.stats)        // `part` (the k-half exchange) is free again: scratch
         chan_partial_sums(oimg, rows_here * Wo, part, p.stats + (size_t)item * 64);
+    STAMP(6);
     }
 }
 
@@ -315,11 +333,13 @@ __global__ void conv_pack_dgrad_kernel(const float *w, __bf16 *out) {
 }
 
 struct ConvDgradParams {
+    long long *stamps;
     const __bf16 *dy;
     const __bf16 *wpack;
     __bf16 *dx;
     int B, H, W, Ho, Wo, Rq;      // Rq rows q per workgroup and class (Rq * W <= 192)
     int pitch;                    // bytes per (padded) dy row in LDS (pick_row_pitch)
+    int flip;                     // second half of the grid takes the wave roles in reverse
 };
 
 // M-tiles (32 pixels each) per wave and class of the input-gradient kernel, and how many A
@@ -347,7 +367,7 @@ __device__ __forceinline__ void conv_dgrad_part(const char *img, const unsigned 
 #pragma unroll
     for (int idx = 0; idx < N; ++idx) {
         acc[idx % DG_NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[idx / DG_NT], a[idx % DG_AD],
-                                                                   acc[idx % DG_NT], 0, 0, 0);
+                                                                   idx < DG_NT ? f32x16{} : acc[idx % DG_NT], 0, 0, 0);
         if (idx + DG_AD < N) a[idx % DG_AD] = frag(idx + DG_AD);
     }
 #pragma unroll
@@ -359,24 +379,57 @@ __device__ __forceinline__ void conv_dgrad_part(const char *img, const unsigned 
     }
 }
 
-__global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradParams p) {
-    extern __shared__ char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// Per item (Rq rows q of the three classes of one utterance) a workgroup spends 168 MFMAs on
+// its longest waves — 5.4k cycles — so everything else in the item loop is written for
+// instruction count and for few dependent LDS round trips (stamped: with runtime divisions in
+// the staging and copy-out loops, and one read -> wait -> store per copied chunk, those cost
+// 15k cycles per item, three times the MFMA loop; an LDS round trip beside a workgroup in its
+// MFMA loop takes ~230 cycles, a VALU instruction ~11):
+//   * roles 0 and 1 (class 0, 21 k-steps each — 7 weight-fragment registers to spare) own the
+//     staging: the item-invariant part of each of their 14 DMA slots' offsets sits in those
+//     spare registers; per item and slot they add the item's row offset and issue the DMA;
+//   * rows above / below the image and the 6 + 6 padding pixels are out-of-range reads (zeros):
+//     the buffer descriptor spans ONE utterance, offsets below 0 wrap past it;
+//   * roles 0 and 1 each finish half of class 0 (three tiles: the other's partial sums come
+//     through LDS, all twelve reads in one round trip); every wave converts, transposes and
+//     copies out its OWN pixels, reads batched ahead of the stores: two barriers per item.
+// role 0: class 0, k-steps 0..20; role 1: class 0, 21..41; role 2: class 1; role 3: class 2.
+// One instantiation per role, entered once per wave: a role that is a run-time value inside one
+// body costs register copies and spills wherever its paths meet.
+template <int ROLE>
+__device__ __forceinline__ void conv_dgrad_wave(const ConvDgradParams &p, char *smem, int lane, int wave) {
+    constexpr int NS = ROLE < 2 ? 21 : 28;                      // k-steps
+    constexpr int FIRST = ROLE == 0 ? 0 : (ROLE == 1 ? 21 : (ROLE == 2 ? 42 : 70));
+    constexpr int R = ROLE < 2 ? 0 : ROLE - 1;                  // class
+    constexpr int HT = DG_NT / 2;
+    constexpr int NT = ROLE < 2 ? HT : DG_NT, T0 = ROLE == 1 ? HT : 0;       // tiles finished here
+    constexpr int GIVE0 = ROLE == 0 ? HT : 0;                                  // tiles given away (roles 0, 1)
+    constexpr int SLOTS = 14;                                   // DMA slots of roles 0 and 1 each
     const int W = p.W, Wo = p.Wo, Rq = p.Rq;
-    // wave 0: class 0, k-steps 0..20; wave 1: class 0, 21..41; wave 2: class 1; wave 3: class 2
-    const int r = wave < 2 ? 0 : wave - 1;
-    // ---- this wave's weight fragments: loaded ONCE per workgroup (persistent grid, as in the
-    // forward kernel: one item per workgroup re-read 100 KB of fragments for 9 KB of dy) --------
+    const unsigned img_bytes = (unsigned)(Rq + 2) * (unsigned)p.pitch;
+    // ---- weight fragments: loaded ONCE per workgroup (persistent grid, as in the forward
+    // kernel: one item per workgroup re-read 100 KB of fragments for 9 KB of dy) ----------------
     bf16x8 bf[28];
     {
-        const int first = wave == 0 ? 0 : (wave == 1 ? 21 : (wave == 2 ? 42 : 70));
-        const int n = wave < 2 ? 21 : 28;
-        const bf16x8 *src = reinterpret_cast<const bf16x8 *>(p.wpack) + (size_t)first * 64 + lane;
+        const bf16x8 *src = reinterpret_cast<const bf16x8 *>(p.wpack) + (size_t)FIRST * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < 28; ++s) bf[s] = s < n ? src[(size_t)s * 64] : bf16x8{};
+        for (int s = 0; s < NS; ++s) bf[s] = src[(size_t)s * 64];
     }
-    const rsrc_words yR = conv_raw_rsrc(p.dy, (unsigned)((size_t)p.B * p.Ho * Wo * 64));
+    // DMA slot k = SLOTS * ROLE + kk = LDS bytes [1024 k + 16 lane, +16) of the linear image (rows
+    // `pitch` apart, pixels 80 bytes apart, 6 padding pixels on both sides of a row): offset of
+    // its dy bytes from the item's first staged row, or a value no item offset brings into range
+    unsigned tab[SLOTS];
+    if (ROLE < 2) {
+#pragma unroll
+        for (int kk = 0; kk < SLOTS; ++kk) {
+            const unsigned beta = (unsigned)(SLOTS * ROLE + kk) * 1024u + (unsigned)lane * 16u;
+            const unsigned row = beta / (unsigned)p.pitch, rem = beta - row * (unsigned)p.pitch;
+            const unsigned col = (rem * 52429u) >> 22, within = rem - col * 80u;        // rem / 80 for rem < 2^16
+            const int wo = (int)col - 6;
+            const bool ok = beta < img_bytes && within < 64u && wo >= 0 && wo < Wo;
+            tab[kk] = ok ? (row * (unsigned)Wo + (unsigned)wo) * 64u + within : 0xC0000000u;
+        }
+    }
     unsigned pixbase[DG_NT];
     const int npix = Rq * W;
 #pragma unroll
@@ -388,81 +441,140 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradPa
     }
     const int nq = (p.H + 2) / 3;                               // q = 0 .. ceil(H / 3) - 1
     const int tiles = (nq + Rq - 1) / Rq, nitems = tiles * p.B;
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int b = item / tiles, q0 = (item - b * tiles) * Rq;
-    __syncthreads();                                            // the previous item's epilogue is done with LDS
-    // ---- stage dy rows q0-2 .. q0+Rq-1, zero-padded by 6 pixels on both sides: LDS-DMA, 1 KiB
-    // of the linear LDS image per instruction; padding slots read out of range = zeros ----------
-    {
-        const unsigned img_bytes = (unsigned)(Rq + 2) * (unsigned)p.pitch;
-        const unsigned soff = (unsigned)b * (unsigned)(p.Ho * Wo * 64);
-        for (unsigned qd = (unsigned)wave; qd * 1024u < img_bytes; qd += 4) {
-            const unsigned beta = qd * 1024u + (unsigned)lane * 16u;
-            const unsigned row = beta / (unsigned)p.pitch, rem = beta - row * (unsigned)p.pitch;
-            const unsigned col = (rem * 52429u) >> 22, within = rem - col * 80u;        // rem / 80 for rem < 2^16
-            const int ho = q0 - 2 + (int)row, wo = (int)col - 6;
-            const bool ok = beta < img_bytes && within < 64u && ho >= 0 && ho < p.Ho && wo >= 0 && wo < Wo;
-            const unsigned voff = ok ? ((unsigned)ho * (unsigned)Wo + (unsigned)wo) * 64u + within : 0x80000000u;
-            conv_dma16(yR, (unsigned)__builtin_amdgcn_readfirstlane((int)(conv_lds_addr(smem) + qd * 1024u)), voff, soff);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    f32x16 acc[DG_NT];
+    const int nslots = (int)((img_bytes + 1023u) / 1024u);
+    // LDS behind the image: [A 12 KB | B 12 KB | class 1 | class 2].  A = role 0's partial sums
+    // of tiles 3..5, then role 1's half of the class-0 image (pixels 96..191, in A's first 6 KB);
+    // B = role 1's partial sums of tiles 0..2, then role 0's half (pixels 0..95).
+    constexpr int HALF = HT * 4 * 64 * 16;
+    char *epi = smem + nslots * 1024;
+    char *part_out = epi + (ROLE == 0 ? 0 : HALF);              // roles 0, 1: the half given away
+    char *part_in = epi + (ROLE == 0 ? HALF : 0);               //             the half received
+    // `ocls` = where pixel 0 of this wave's class would be (role 1 holds pixels 96.. only)
+    char *ocls = ROLE == 0 ? epi + HALF : ROLE == 1 ? epi - T0 * 2048 : epi + 2 * HALF + (R - 1) * DG_PIX * 64;
+    const unsigned img_lds = conv_lds_addr(smem);
+    const unsigned item_bytes = (unsigned)(p.Ho * Wo * 64);
+    auto stage = [&](int it) {          // roles 0 and 1
+        const int b = it / tiles, q0 = (it - b * tiles) * Rq;
+        const rsrc_words yR = conv_raw_rsrc(reinterpret_cast<const char *>(p.dy) + (size_t)b * item_bytes, item_bytes);
+        const unsigned base = (unsigned)((q0 - 2) * Wo * 64);
 #pragma unroll
-    for (int i = 0; i < DG_NT; ++i)
+        for (int kk = 0; kk < SLOTS; ++kk)
+            if (SLOTS * ROLE + kk < nslots)
+                conv_dma16(yR, (unsigned)__builtin_amdgcn_readfirstlane((int)(img_lds + (SLOTS * ROLE + kk) * 1024u)),
+                           tab[kk] + base, 0u);
+    };
+    if (ROLE < 2 && (int)blockIdx.x < nitems) stage(blockIdx.x);
+    // epilogue constants: a wave's pixels are written 8 bytes per lane (pixel = lane & 31 of
+    // tile i, ci quad g, half lane >> 5) with the 16-byte chunks of a pixel XORed by
+    // (pixel >> 2) & 3 — the 32 pixels of a write otherwise sit on 4 bank groups — and read back
+    // 16 bytes per lane in pixel order
+    const unsigned wr_base = (unsigned)((lane & 31) * 64 + ((lane >> 5) << 3));
+    const unsigned wr_swz = (unsigned)((lane >> 2) & 3);
+    const unsigned qmagic = 65536u / (unsigned)W + 1u;          // m / W = (m * qmagic) >> 16 for m < 2^12
+    const int cls_chunks = Rq * W * 4;
+    int nst = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++nst) {
+        const int b = item / tiles, q0 = (item - b * tiles) * Rq;
+        STAMP(0);
+        if (ROLE < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                // image landed; the previous item's epilogue is done with LDS
+        f32x16 acc[DG_NT];              // (the first k-step starts them from a literal zero)
+        STAMP(1);
+        conv_dgrad_part<NS, ROLE == 1 ? 21 : 0>(smem, pixbase, p.pitch, bf, acc);
+        STAMP(2);
+        if (ROLE < 2) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-    if (wave == 0) conv_dgrad_part<21, 0>(smem, pixbase, p.pitch, bf, acc);
-    else if (wave == 1) conv_dgrad_part<21, 21>(smem, pixbase, p.pitch, bf, acc);
-    else conv_dgrad_part<28, 0>(smem, pixbase, p.pitch, bf, acc);
-    __syncthreads();
-
-    // ---- epilogue: wave 1 -> wave 0 partial sum; [class][pixel][ci] bf16 image (the 16-byte
-    // chunks of a pixel XORed with (pixel >> 2) & 3: the 32 pixels of an 8-byte write otherwise
-    // sit on 4 bank groups); coalesced rows out --------------------------------------------------
-    f32x4 *part = reinterpret_cast<f32x4 *>(smem);              // [DG_NT][4][64] x 16 B = 24 KB
-    char *oimg = smem + DG_NT * 4 * 64 * 16;                    // [3][DG_PIX][32] bf16
-    if (wave == 1) {
+            for (int i = 0; i < HT; ++i)
 #pragma unroll
-        for (int i = 0; i < DG_NT; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                part[(i * 4 + g) * 64 + lane] = f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
-    }
-    __syncthreads();
-    if (wave != 1) {
-#pragma unroll
-        for (int i = 0; i < DG_NT; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
-                if (wave == 0) {
-                    const f32x4 o = part[(i * 4 + g) * 64 + lane];
-                    v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16 &c = acc[GIVE0 + i];
+                    *reinterpret_cast<f32x4 *>(part_out + ((i * 4 + g) * 64 + lane) * 16) =
+                        f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
                 }
-                const int m = 32 * i + (lane & 31);
-                bf16x4 o4 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                *reinterpret_cast<bf16x4 *>(oimg + (r * DG_PIX + m) * 64 + ((g ^ ((m >> 2) & 3)) << 4) + ((lane >> 5) << 3)) = o4;
-            }
-    }
-    __syncthreads();
-    {
-        // output rows h = 3 (q0 + q) + rc, one 64 W-byte row each
-        const int chunks_per_row = W * 4;
-        const int total = 3 * Rq * chunks_per_row;
-        char *xb = reinterpret_cast<char *>(p.dx) + (size_t)b * p.H * W * 64;
-        for (int c = tid; c < total; c += 256) {
-            const int rowi = c / chunks_per_row, within = c - rowi * chunks_per_row;
-            const int rc = rowi / Rq, q = rowi - rc * Rq;
-            const int h = 3 * (q0 + q) + rc;
-            const int m = q * W + (within >> 2), k = within & 3;
-            if (h < p.H)
-                *reinterpret_cast<u32x4 *>(xb + (size_t)h * W * 64 + (size_t)within * 16) =
-                    *reinterpret_cast<const u32x4 *>(oimg + (rc * DG_PIX + m) * 64 + ((k ^ ((m >> 2) & 3)) << 4));
         }
+        STAMP(3);
+        __syncthreads();                // image no longer read; the partial sums are in LDS
+        STAMP(4);
+        if (ROLE < 2 && item + (int)gridDim.x < nitems) stage(item + gridDim.x);
+        // ---- convert tiles [T0, T0 + NT) -> this wave's pixels in LDS -----------------------------
+        {
+            constexpr int E = NT * 4, RD = ROLE < 2 ? E / 2 : E;        // entries = (tile, ci quad)
+#pragma unroll
+            for (int e0 = 0; e0 < E; e0 += RD) {
+                f32x4 o[ROLE < 2 ? RD : 1];
+                if (ROLE < 2) {         // (a round's reads all before its writes: they share LDS,
+                                        //  and a write never reaches past the entries read so far)
+#pragma unroll
+                    for (int k = 0; k < RD; ++k)
+                        o[k] = *reinterpret_cast<const f32x4 *>(part_in + ((e0 + k) * 64 + lane) * 16);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int k = 0; k < RD; ++k) {
+                    const int i = (e0 + k) / 4, g = (e0 + k) % 4;
+                    const f32x16 &c = acc[T0 + i];
+                    f32x4 v = {c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+                    if (ROLE < 2) v += o[k];
+                    bf16x4 o4 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<bf16x4 *>(ocls + (T0 + i) * 2048 + wr_base + (((unsigned)g ^ wr_swz) << 4)) = o4;
+                }
+            }
+        }
+        STAMP(5);
+        {
+            // output rows h = 3 (q0 + q) + R, W x 64 bytes each; chunk e of the class image is bytes
+            // [16 e, +16) of pixel m = e >> 2: 16 e bytes into row q's start + q rows of the other
+            // classes.  Six reads (one LDS round trip), then their stores.
+            char *xb = reinterpret_cast<char *>(p.dx) + ((size_t)b * p.H + 3 * q0 + R) * W * 64;
+            const int qlim = (p.H - R + 2) / 3 - q0;                 // rows q < qlim exist
+            int e0 = T0 * 128 + lane;
+            asm volatile("" : "+v"(e0));        // (recompute the chunk addresses per item: hoisted, they spill)
+#pragma unroll
+            for (int rd = 0; rd < NT * 2; rd += 6) {
+                u32x4 v[6];
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const unsigned e = (unsigned)(e0 + 64 * (rd + it)), m = e >> 2;
+                    v[it] = *reinterpret_cast<const u32x4 *>(ocls + ((e ^ ((m >> 2) & 3u)) << 4));
+                }
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const unsigned e = (unsigned)(e0 + 64 * (rd + it)), m = e >> 2, q = (m * qmagic) >> 16;
+                    if ((int)e < cls_chunks && (int)q < qlim)
+                        *reinterpret_cast<u32x4 *>(xb + (size_t)(e * 16u + q * (unsigned)(2 * W * 64))) = v[it];
+                }
+            }
+        }
+        STAMP(6); STAMP(7);
     }
-    }
+}
+
+// Per item (Rq rows q of the three classes of one utterance) a workgroup spends 168 MFMAs on
+// its longest waves — 5.4k cycles — so everything else in the item loop is written for
+// instruction count and for few dependent LDS round trips (stamped: with runtime divisions in
+// the staging and copy-out loops, and one read -> wait -> store per copied chunk, those cost
+// 15k cycles per item, three times the MFMA loop; an LDS round trip beside a workgroup in its
+// MFMA loop takes ~230 cycles, a VALU instruction ~11):
+//   * roles 0 and 1 (class 0, 21 k-steps each: registers to spare) own the staging: the
+//     item-invariant part of each of their 14 DMA slots' offsets sits in registers; per item
+//     and slot they add the item's row offset and issue the DMA;
+//   * rows above / below the image and the 6 + 6 padding pixels are out-of-range reads (zeros):
+//     the buffer descriptor spans ONE utterance, offsets below 0 wrap past it;
+//   * roles 0 and 1 each finish half of class 0 (three tiles: the other's partial sums come
+//     through LDS, six reads per round trip); every wave converts, transposes and copies out
+//     its OWN pixels, reads batched ahead of the stores: two barriers per item.
+// Roles 2 and 3 carry 28 k-steps against 21: the second half of the grid (the workgroups that
+// share a CU with the first half's) takes the roles in reverse wave order, so that every SIMD
+// gets one long and one short wave.
+__global__ __launch_bounds__(256, 2) void conv7x7c32_dgrad_s3_kernel(ConvDgradParams p) {
+    extern __shared__ char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = __builtin_amdgcn_readfirstlane(p.flip && blockIdx.x >= (gridDim.x >> 1) ? 3 - wave : wave);
+    if (role == 0) conv_dgrad_wave<0>(p, smem, lane, wave);
+    else if (role == 1) conv_dgrad_wave<1>(p, smem, lane, wave);
+    else if (role == 2) conv_dgrad_wave<2>(p, smem, lane, wave);
+    else conv_dgrad_wave<3>(p, smem, lane, wave);
 }
 
 
@@ -791,6 +903,42 @@ __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *p
 
 }  // namespace
 
+
+#ifdef CONV_STAMPS
+static long long *stamp_buf() {
+    static long long *d = nullptr;
+    if (!d && getenv("ASR_CONV_STAMPS")) { hipMalloc(&d, 4 * 64 * 8 * 8); }
+    if (d) hipMemset(d, 0, 4 * 64 * 8 * 8);
+    return d;
+}
+static hipEvent_t stamp_ev[2];
+static void stamp_begin(hipStream_t s) {
+    if (!stamp_ev[0]) { hipEventCreate(&stamp_ev[0]); hipEventCreate(&stamp_ev[1]); }
+    hipEventRecord(stamp_ev[0], s);
+}
+static void stamp_dump(const char *name, long long *d, hipStream_t s) {
+    if (!d) return;
+    hipEventRecord(stamp_ev[1], s);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, stamp_ev[0], stamp_ev[1]);
+    static long long h[4 * 64 * 8];
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    for (int w = 0; w < 4; ++w)
+        for (int lo = 2; lo < 30; lo += 14) {
+            double avg[9] = {0};
+            for (int it = lo; it < lo + 12; ++it) {
+                for (int k = 1; k < 8; ++k) avg[k] += (double)(h[(w * 64 + it) * 8 + k] - h[(w * 64 + it) * 8 + k - 1]) / 12;
+                avg[8] += (double)(h[(w * 64 + it + 1) * 8] - h[(w * 64 + it) * 8]) / 12;
+            }
+            fprintf(stderr, "%s wave %d items %d..%d avg:", name, w, lo, lo + 11);
+            for (int k = 1; k < 8; ++k) fprintf(stderr, " %6.0f", avg[k]);
+            fprintf(stderr, "  | total %.0f\n", avg[8]);
+        }
+    fprintf(stderr, "%s kernel %.1f us; items 0..30 of block 7 took %lld ticks\n", name, ms * 1e3, h[30 * 8] - h[0]);
+}
+#endif
+
 extern "C" int64_t asr_conv7x7c32_workspace_bytes(void) {
     // two packed weight images (forward, input gradient) + the weight gradient's partial sums
     return (int64_t)KSTEPS * 64 * 8 * 2 * 2 + (int64_t)WGRAD_WGS * 49 * 1024 * 4 + 256;
@@ -832,7 +980,16 @@ extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ASR_EUNSUPPORTED;
+#ifdef CONV_STAMPS
+    p.stamps = stamp_buf();
+    stamp_begin(s);
+#else
+    p.stamps = nullptr;
+#endif
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+#ifdef CONV_STAMPS
+    stamp_dump("fwd", p.stamps, s);
+#endif
     if (chan_sums) {
         hipLaunchKernelGGL(zero_chan_sums_kernel, dim3(1), dim3(64), 0, s, chan_sums);
         hipLaunchKernelGGL(chan_sums_reduce_kernel, dim3(64), dim3(1024), 0, s, p.stats, nitems, chan_sums);
@@ -855,9 +1012,11 @@ extern "C" int asr_conv7x7c32_bwd_data_bf16(const void *dy, const float *w, int 
     // (the image is filled in whole 1 KiB DMA blocks)
     const size_t img = ((size_t)(Rq + 2) * pitch + 1023) / 1024 * 1024;
     if ((int64_t)B * Ho * Wo * 64 >= (1ll << 31)) return ASR_EUNSUPPORTED;     // 32-bit buffer offsets
-    const size_t epi = (size_t)DG_NT * 4 * 64 * 16 + (size_t)3 * DG_PIX * CH * 2;
-    const size_t lds = img > epi ? img : epi;
-    if (lds > 80 * 1024) return ASR_EUNSUPPORTED;
+    // epilogue beside the image: the partial-sum exchange (class 0 of the output image reuses
+    // its first half) + classes 1 and 2
+    const size_t epi = (size_t)DG_NT * 4 * 64 * 16 + (size_t)2 * DG_PIX * CH * 2;
+    const size_t lds = img + epi;
+    if (lds > 80 * 1024 || img > 28 * 1024) return ASR_EUNSUPPORTED;          // (28 DMA slots)
     hipStream_t s = (hipStream_t)stream;
     __bf16 *wpack = (__bf16 *)workspace + (size_t)KSTEPS * 64 * 8;
     hipLaunchKernelGGL(conv_pack_dgrad_kernel, dim3((KSTEPS * 64 * 8 + 255) / 256), dim3(256), 0, s, w, wpack);
@@ -868,13 +1027,23 @@ extern "C" int asr_conv7x7c32_bwd_data_bf16(const void *dy, const float *w, int 
     const int nitems = ((nq + Rq - 1) / Rq) * B;
     int wgs = 2 * conv_cu_count();
     if (wgs <= 0) wgs = 512;
+    p.flip = wgs <= nitems;                                      // (two workgroups on every CU)
     if (wgs > nitems) wgs = nitems;
     const dim3 grid(wgs);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)conv7x7c32_dgrad_s3_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ASR_EUNSUPPORTED;
+#ifdef CONV_STAMPS
+    p.stamps = stamp_buf();
+    stamp_begin(s);
+#else
+    p.stamps = nullptr;
+#endif
     hipLaunchKernelGGL(conv7x7c32_dgrad_s3_kernel, grid, dim3(256), lds, s, p);
+#ifdef CONV_STAMPS
+    stamp_dump("dgrad", p.stamps, s);
+#endif
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
