@@ -7,7 +7,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-CASES = [(2, 58, 17, 3), (3, 31, 13, 1), (1, 1006, 17, 3), (5, 40, 23, 3), (2, 7, 7, 1)]
+# (the last case has more (utterance, row block) items than the persistent grid has workgroups)
+CASES = [(2, 58, 17, 3), (3, 31, 13, 1), (1, 1006, 17, 3), (5, 40, 23, 3), (2, 7, 7, 1), (24, 1006, 17, 3)]
 
 
 def _inputs(B, H, W, seed):
@@ -40,7 +41,9 @@ def test_conv_forward_matches_conv2d(B, H, W, sh):
     assert rel < 2e-2
 
 
-@pytest.mark.parametrize('B,H,W', [(2, 58, 17), (1, 1006, 17), (3, 40, 23), (2, 9, 7), (2, 62, 17)])
+# (24 x 31 row blocks: more items than workgroups, the grid's second half runs the reversed wave roles)
+@pytest.mark.parametrize('B,H,W', [(2, 58, 17), (1, 1006, 17), (3, 40, 23), (2, 9, 7), (2, 62, 17), (24, 1006, 17),
+                                   (2, 100, 48), (3, 50, 8)])
 def test_conv_input_gradient_matches_conv2d(B, H, W):
     from att_speech import _native
     x, w = _inputs(B, H, W, B * 7 + H)
