@@ -162,7 +162,7 @@ struct ConvFwdParams {
     const __bf16 *x;
     const __bf16 *wpack;
     __bf16 *y;
-    float *stats;                 // [workgroups][64] channel sums of the outputs, or null
+    float *stats;                 // [workgroups][4 waves][64] channel sums of the outputs, or null
     int B, H, W, Ho, Wo, R;       // R output rows per workgroup (R * Wo <= FWD_PIX)
     int pitch;                    // bytes per image row in LDS (pick_row_pitch)
 };
@@ -172,10 +172,23 @@ struct ConvFwdParams {
 // waited for the LDS read issued right in front of it (ds_read -> s_waitcnt lgkmcnt(0) ->
 // v_mfma, 147 times: MFMA-busy 19 %).  With two, three fragments are in flight.
 constexpr int FWD_NT = 2, FWD_PIX = 2 * FWD_NT * 32, FWD_AD = 3;
+constexpr int FWD_MAXQ = 15;      // DMA slots per wave (the image has at most 4 * FWD_MAXQ KiB)
+
+// 64 lanes x 16 bytes to a bounds-checked raw buffer (out-of-range lanes are dropped): always
+// exactly one VMEM instruction, so the `s_waitcnt vmcnt(N)` counted around it stays exact.
+// (The builtin, not inline asm: a first asm version had its data registers overwritten by the
+// next VALU instruction before the store had read them — 2 wait states the compiler inserts
+// only for stores it can see.)
+__device__ __forceinline__ void conv_store16(const void *base, unsigned bytes, u32x4 v, unsigned voff) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
 
 // one k-half (49 k-steps) of the product for FWD_NT M-tiles: the A fragments are read FWD_AD
 // MFMAs ahead into a rotating register set, the order pinned (sched_group_barrier: the
-// scheduler otherwise sinks every read next to its use again)
+// scheduler otherwise sinks every read next to its use again).  Operands swapped (weights as
+// the MFMA's A, pixels as its B): a lane ends up with 4 consecutive co of one pixel per
+// register quad.  The first k-step starts the accumulators from a literal zero.
 template <int SH, int KH>
 __device__ __forceinline__ void conv_fwd_half(const char *img, const unsigned (&pixbase)[FWD_NT], int pitch,
                                               const bf16x8 (&bf)[49], f32x16 (&acc)[FWD_NT]) {
@@ -192,9 +205,15 @@ __device__ __forceinline__ void conv_fwd_half(const char *img, const unsigned (&
     for (int d = 0; d < FWD_AD; ++d) a[d] = frag(d);
 #pragma unroll
     for (int idx = 0; idx < N; ++idx) {
-        acc[idx % FWD_NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[idx % FWD_AD], bf[idx / FWD_NT],
-                                                                    acc[idx % FWD_NT], 0, 0, 0);
+        acc[idx % FWD_NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[idx / FWD_NT], a[idx % FWD_AD],
+                                                                    idx < FWD_NT ? f32x16{} : acc[idx % FWD_NT], 0, 0, 0);
         if (idx + FWD_AD < N) a[idx % FWD_AD] = frag(idx + FWD_AD);
+        // (k-step by k-step: the group barriers below fix how many reads and MFMAs alternate, not
+        //  WHICH — left alone the scheduler finishes one tile first and parks the other's
+        //  fragments, then the weights, in scratch)
+        // (not behind the last k-step: the asm would stand between the MFMAs and the first reader
+        //  of their results, and the wait states that reader needs are counted from its producer)
+        if (idx % FWD_NT == FWD_NT - 1 && idx + 1 < N) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
     }
 #pragma unroll
     for (int d = 0; d < FWD_AD; ++d) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -205,54 +224,39 @@ __device__ __forceinline__ void conv_fwd_half(const char *img, const unsigned (&
     }
 }
 
-template <int SH>
-__global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p) {
-    extern __shared__ char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kh = wave & 1, mh = wave >> 1;
+// One instantiation per k-half (the wave's role; see conv_dgrad_wave).  Per item a wave spends
+// 98 MFMAs (3.1 k cycles); the first persistent version spent 10 k more per item on staging
+// with run-time divisions (5.2 k), a serialized exchange of the k-halves (2.6 k) and the
+// copy-out (1 k).  Now:
+//   * the item-invariant part of a wave's <= 15 DMA slot offsets is worked out once and parked
+//     in LDS (the 196 weight registers leave no room): per item a table read, one add and
+//     the DMA; the buffer descriptor spans one utterance, rows past it read out of range;
+//   * the next item's image is in flight under the epilogue (its own LDS area);
+//   * the two waves of a pixel half finish one tile each: the other tile's partial sums go
+//     through LDS (4 x 16 bytes per lane each way), every wave converts, transposes (LDS,
+//     8-byte writes / 16-byte reads, chunks XOR-swizzled), sums the statistics of and stores
+//     its OWN 32 pixels: two barriers per item.
+template <int SH, int KH>
+__device__ __forceinline__ void conv_fwd_wave(const ConvFwdParams &p, char *smem, int lane, int wave) {
+    const int mh = wave >> 1;
     const int W = p.W, Wo = p.Wo, R = p.R;
     const int in_rows = SH * (R - 1) + KS;
-
-    // ---- weight fragments of this wave's k-half: loaded ONCE per workgroup.  The grid is
-    // persistent (two workgroups per CU, each walking the (utterance, row block) items): with
-    // one item per workgroup every workgroup re-read its 196 KB of fragments from L2 — 3.5 GB
-    // per call against 0.6 GB of input, and at the ~25 B/clk a CU takes in that, not the MFMA
-    // loop, set the pace (469 us with or without the pipelined loop above).
-    bf16x8 bf[49];
-    {
-        const bf16x8 *src = reinterpret_cast<const bf16x8 *>(p.wpack) + (size_t)(49 * kh) * 64 + lane;
-#pragma unroll
-        for (int s = 0; s < 49; ++s) bf[s] = src[(size_t)s * 64];
+    const unsigned img_bytes = (unsigned)in_rows * (unsigned)p.pitch;
+    const int nslots = (int)((img_bytes + 1023u) / 1024u);
+    // LDS: [image: nslots KiB | slot table: nslots x 64 u16 | exchange: 4 waves x 4 KiB]
+    unsigned short *tab = reinterpret_cast<unsigned short *>(smem + nslots * 1024);
+    char *xch = smem + nslots * (1024 + 128);
+    // DMA slot q (this wave's: q = wave, wave + 4, ...) = LDS bytes [1024 q + 16 lane, +16) of the
+    // linear image (rows `pitch` apart, pixels 80 bytes apart): 16-byte index of its x bytes from
+    // the item's first input row, or 0xffff for padding.  Written and read by the same lane.
+#pragma unroll 1
+    for (int q = wave; q < nslots; q += 4) {
+        const unsigned beta = (unsigned)q * 1024u + (unsigned)lane * 16u;
+        const unsigned row = beta / (unsigned)p.pitch, rem = beta - row * (unsigned)p.pitch;
+        const unsigned pix = (rem * 52429u) >> 22, within = rem - pix * 80u;       // rem / 80 for rem < 2^16
+        const bool ok = beta < img_bytes && pix < (unsigned)W && within < 64u;
+        tab[q * 64 + lane] = (unsigned short)(ok ? (row * (unsigned)W + pix) * 4u + (within >> 4) : 0xffffu);
     }
-    const rsrc_words xR = conv_raw_rsrc(p.x, (unsigned)((size_t)p.B * p.H * W * 64));
-    const int tiles = (p.Ho + R - 1) / R, nitems = tiles * p.B;
-    int nst = 0;
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++nst) {
-    const int b = item / tiles, ho0 = (item - b * tiles) * R;
-    const int h0 = ho0 * SH;
-    __syncthreads();                                            // the previous item's epilogue is done with LDS
-    STAMP(0);
-    // ---- stage the input rows: global -> LDS by LDS-DMA, 1 KiB of the padded image per
-    // instruction (with 196 weight registers there is none to stage through, and a load ->
-    // LDS-store loop one chunk at a time cost 20k cycles per item).  The image is linear in
-    // LDS — rows `pitch` bytes apart, pixels 80 bytes apart — so each lane works out which
-    // (row, pixel, 16-byte part) its slot belongs to; slots in the padding, past the image
-    // row or past the tensor read out of range and write zeros.
-    {
-        const unsigned img_bytes = (unsigned)in_rows * (unsigned)p.pitch;
-        const unsigned soff = (unsigned)b * (unsigned)(p.H * W * 64);
-        for (unsigned q = (unsigned)wave; q * 1024u < img_bytes; q += 4) {
-            const unsigned beta = q * 1024u + (unsigned)lane * 16u;
-            const unsigned row = beta / (unsigned)p.pitch, rem = beta - row * (unsigned)p.pitch;
-            const unsigned pix = (rem * 52429u) >> 22, within = rem - pix * 80u;       // rem / 80 for rem < 2^16
-            const bool ok = beta < img_bytes && pix < (unsigned)W && within < 64u && h0 + (int)row < p.H;
-            const unsigned voff = ok ? ((unsigned)(h0 + (int)row) * (unsigned)W + pix) * 64u + within : 0x80000000u;
-            conv_dma16(xR, (unsigned)__builtin_amdgcn_readfirstlane((int)(conv_lds_addr(smem) + q * 1024u)), voff, soff);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    STAMP(1);
     // ---- per-lane pixel bases of this wave's M-tiles -------------------------------------------
     unsigned pixbase[FWD_NT];
     const int npix = R * Wo;
@@ -263,53 +267,149 @@ __global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p)
         const int r = m / Wo, wo = m - r * Wo;
         pixbase[i] = (unsigned)((r * SH) * p.pitch + wo * PIX + (lane >> 5) * 16);
     }
-    __syncthreads();
-    STAMP(2);
-    f32x16 acc[FWD_NT];
+    const int tiles = (p.Ho + R - 1) / R, nitems = tiles * p.B;
+    const unsigned img_lds = conv_lds_addr(smem);
+    const unsigned utt_bytes = (unsigned)(p.H * W * 64);
+    auto stage = [&](int it, int ln) {
+        const int b = it / tiles, ho0 = (it - b * tiles) * R;
+        const rsrc_words xR = conv_raw_rsrc(reinterpret_cast<const char *>(p.x) + (size_t)b * utt_bytes, utt_bytes);
+        const unsigned base = (unsigned)(ho0 * SH * W * 64);
+        // (five slots per LDS round trip, fenced: the compiler otherwise gathers every independent
+        //  LDS read of the epilogue at its top — more registers than the weights leave)
 #pragma unroll
-    for (int i = 0; i < FWD_NT; ++i)
+        for (int k0 = 0; k0 < FWD_MAXQ; k0 += 5) {
+            unsigned t[5];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-    if (kh == 0) conv_fwd_half<SH, 0>(smem, pixbase, p.pitch, bf, acc);
-    else conv_fwd_half<SH, 1>(smem, pixbase, p.pitch, bf, acc);
-    STAMP(3);
-    __syncthreads();                                            // image no longer needed
-    STAMP(4);
-
-    // ---- sum the two k-halves, convert, write [pixel][co] rows to LDS, copy out coalesced -----
-    float *part = reinterpret_cast<float *>(smem);              // [2 mh][FWD_NT][16][64] fp32
-    __bf16 *oimg = reinterpret_cast<__bf16 *>(smem + 2 * FWD_NT * 16 * 64 * 4);   // [FWD_PIX][32] bf16
-    if (kh == 1) {
+            for (int k = 0; k < 5; ++k)
+                if (wave + 4 * (k0 + k) < nslots) t[k] = tab[(wave + 4 * (k0 + k)) * 64 + ln];
 #pragma unroll
-        for (int i = 0; i < FWD_NT; ++i)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) part[((mh * FWD_NT + i) * 16 + j) * 64 + lane] = acc[i][j];
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-        for (int i = 0; i < FWD_NT; ++i)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float v = acc[i][j] + part[((mh * FWD_NT + i) * 16 + j) * 64 + lane];
-                const int m = 32 * (FWD_NT * mh + i) + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
-                oimg[m * CH + (lane & 31)] = (__bf16)v;
-            }
-    }
-    __syncthreads();
-    STAMP(5);
-    const int rows_here = (p.Ho - ho0) < R ? (p.Ho - ho0) : R;
+            for (int k = 0; k < 5; ++k)
+                if (wave + 4 * (k0 + k) < nslots)
+                    conv_dma16(xR, (unsigned)__builtin_amdgcn_readfirstlane((int)(img_lds + (unsigned)(wave + 4 * (k0 + k)) * 1024u)),
+                               t[k] == 0xffffu ? 0x80000000u : t[k] * 16u + base, 0u);
+            asm volatile("" ::: "memory");
+        }
+    };
+    if ((int)blockIdx.x < nitems) stage(blockIdx.x, lane);
+    // epilogue constants (see conv_dgrad_wave)
+    const int partner = wave ^ 1, tile = FWD_NT * mh + KH;      // the M-tile this wave finishes
+    char *give = xch + wave * 4096, *take = xch + partner * 4096;
+    // running channel statistics of this wave's tiles, per lane (channel lane & 31, pixels
+    // 16 (lane >> 5) ..): parked in LDS like everything else that would be live across the MFMA loop
+    float *run = reinterpret_cast<float *>(xch + 4 * 4096) + wave * 128;
+    run[lane] = 0.f;
+    run[64 + lane] = 0.f;
+    // ---- weight fragments of this wave's k-half: loaded ONCE per workgroup.  The grid is
+    // persistent (two workgroups per CU, each walking the (utterance, row block) items): with
+    // one item per workgroup every workgroup re-read its 196 KB of fragments from L2 — 3.5 GB
+    // per call against 0.6 GB of input, and at the ~25 B/clk a CU takes in that, not the MFMA
+    // loop, set the pace (469 us with or without the pipelined loop above).
+    bf16x8 bf[49];
     {
-        const int chunks = rows_here * Wo * 4;
-        char *yb = reinterpret_cast<char *>(p.y) + ((size_t)b * p.Ho + ho0) * Wo * 64;
-        for (int c = tid; c < chunks; c += 256)
-            *reinterpret_cast<u32x4 *>(yb + (size_t)c * 16) =
-                *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(oimg) + (size_t)c * 16);
+        const bf16x8 *src = reinterpret_cast<const bf16x8 *>(p.wpack) + (size_t)(49 * KH) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 49; ++s) bf[s] = src[(size_t)s * 64];
     }
-    if (p.stats)        // `part` (the k-half exchange) is free again: scratch
-        chan_partial_sums(oimg, rows_here * Wo, part, p.stats + (size_t)item * 64);
-    STAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int nst = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++nst) {
+        const int b = item / tiles, ho0 = (item - b * tiles) * R;
+        STAMP(0);
+        // the image's DMAs are older than the previous item's two stores (VMEM retires in order)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __syncthreads();                // image landed; the previous item's epilogue is done with LDS
+        STAMP(1);
+        f32x16 acc[FWD_NT];
+        // (scheduling fences: without them the scheduler finishes the tile that is given away
+        //  first, reads a dozen A fragments ahead to do so and spills the weights to make room)
+        __builtin_amdgcn_sched_barrier(0);
+        conv_fwd_half<SH, KH>(smem, pixbase, p.pitch, bf, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(2);
+        // (the lane index is worked out again here, per item: the weights, the accumulators and
+        //  the fragments in flight leave the MFMA loop no register for anything else)
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x16 &c = acc[1 - KH];
+            *reinterpret_cast<f32x4 *>(give + (g * 64 + ln) * 16) = f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+        }
+        STAMP(3);
+        __syncthreads();                // image no longer read; the partial sums are in LDS
+        STAMP(4);
+        {
+            const unsigned wr_off = (unsigned)((ln & 31) * 64 + ((ln >> 5) << 3));
+            const unsigned wr_swz = (unsigned)((ln >> 2) & 3);
+            f32x4 o[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) o[g] = *reinterpret_cast<const f32x4 *>(take + (g * 64 + ln) * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (reads before the writes below: same LDS)
+            STAMP(5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16 &c = acc[KH];
+                f32x4 v = {c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+                v = KH == 0 ? v + o[g] : o[g] + v;              // k-half 0 + k-half 1 on both sides
+                bf16x4 o4 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4 *>(take + wr_off + (((unsigned)g ^ wr_swz) << 4)) = o4;
+            }
+        }
+        // (behind the exchange, not in front of it: with the accumulators still live the slot
+        //  offsets do not fit next to the 196 weight registers)
+        asm volatile("" ::: "memory");
+        STAMP(6);
+        if (item + (int)gridDim.x < nitems) stage(item + gridDim.x, ln);
+        const int rows_here = (p.Ho - ho0) < R ? (p.Ho - ho0) : R;
+        const int nvalid = rows_here * Wo - 32 * tile;           // this tile's pixels that exist
+        if (p.stats) {
+            const unsigned ch = (unsigned)ln & 31u;
+            const unsigned p0 = (unsigned)(ln >> 5) * 16u;
+            float ssum = 0.f, qsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned pp = p0 + (unsigned)k;
+                const unsigned short raw = *reinterpret_cast<const unsigned short *>(
+                    take + pp * 64u + ((((ch >> 3) ^ (pp >> 2)) & 3u) << 4) + (ch & 7u) * 2u);
+                const float v = (int)pp < nvalid ? __uint_as_float((unsigned)raw << 16) : 0.f;
+                ssum += v;
+                qsum += v * v;
+                if ((k & 3) == 3) asm volatile("" ::: "memory");
+            }
+            run[ln] += ssum;
+            run[64 + ln] += qsum;
+        }
+        asm volatile("" ::: "memory");
+        STAMP(7);
+        {
+            // the tile's 2 KiB = bytes [2048 tile, +2048) of the item's output rows
+            const char *ybase = reinterpret_cast<const char *>(p.y) + ((size_t)b * p.Ho + ho0) * Wo * 64;
+            u32x4 v[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const unsigned e = (unsigned)(ln + 64 * it);
+                v[it] = *reinterpret_cast<const u32x4 *>(take + ((e ^ ((e >> 4) & 3u)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+                conv_store16(ybase, (unsigned)(rows_here * Wo * 64), v[it], (unsigned)(2048 * tile + 16 * (ln + 64 * it)));
+        }
     }
+    if (p.stats) {
+        // per-wave partial sums: lanes 0..31 the channel sums, 32..63 the sums of squares
+        const int ln = threadIdx.x & 63;
+        const float a0 = run[ln & 31] + run[32 + (ln & 31)], a1 = run[64 + (ln & 31)] + run[96 + (ln & 31)];
+        p.stats[((size_t)blockIdx.x * 4 + wave) * 64 + ln] = ln < 32 ? a0 : a1;
+    }
+}
+
+template <int SH>
+__global__ __launch_bounds__(256, 2) void conv7x7c32_fwd_kernel(ConvFwdParams p) {
+    extern __shared__ char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((wave & 1) == 0) conv_fwd_wave<SH, 0>(p, smem, lane, wave);
+    else conv_fwd_wave<SH, 1>(p, smem, lane, wave);
 }
 
 
@@ -956,11 +1056,11 @@ extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int
     int R = FWD_PIX / Wo;
     if (R > 16) R = 16;
     const int pitch = pick_row_pitch(W * PIX, Wo, stride_h, R * Wo, 2 * FWD_NT);
-    // (the image is filled in whole 1 KiB DMA blocks)
+    // (the image is filled in whole 1 KiB DMA blocks; behind it the slot table and the exchange area)
     const size_t img = ((size_t)(stride_h * (R - 1) + KS) * pitch + 1023) / 1024 * 1024;
-    if ((int64_t)B * H * W * 64 >= (1ll << 31)) return ASR_EUNSUPPORTED;       // 32-bit buffer offsets
-    const size_t epi = (size_t)2 * FWD_NT * 16 * 64 * 4 + (size_t)FWD_PIX * CH * 2 + 2048;
-    const size_t lds = img > epi ? img : epi;
+    if ((int64_t)H * W * 64 >= (1ll << 31)) return ASR_EUNSUPPORTED;           // 32-bit buffer offsets
+    if (img > (size_t)4 * FWD_MAXQ * 1024) return ASR_EUNSUPPORTED;
+    const size_t lds = img + img / 8 + 4 * 4096 + 2048;
     if (lds > 80 * 1024) return ASR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     __bf16 *wpack = (__bf16 *)workspace;
@@ -975,7 +1075,7 @@ extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int
     const dim3 grid(wgs);
     // the weight gradient's partial-sum area doubles as the statistics' (never live together)
     p.stats = chan_sums ? (float *)((char *)workspace + (size_t)KSTEPS * 64 * 8 * 2 * 2) : nullptr;
-    if (chan_sums && (int64_t)nitems * 64 * 4 > (int64_t)WGRAD_WGS * 49 * 1024 * 4) return ASR_EUNSUPPORTED;
+    if (chan_sums && (int64_t)wgs * 4 * 64 * 4 > (int64_t)WGRAD_WGS * 49 * 1024 * 4) return ASR_EUNSUPPORTED;
     void (*kern)(ConvFwdParams) = stride_h == 3 ? conv7x7c32_fwd_kernel<3> : conv7x7c32_fwd_kernel<1>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -992,7 +1092,7 @@ extern "C" int asr_conv7x7c32_fwd_bf16(const void *x, const float *w, int B, int
 #endif
     if (chan_sums) {
         hipLaunchKernelGGL(zero_chan_sums_kernel, dim3(1), dim3(64), 0, s, chan_sums);
-        hipLaunchKernelGGL(chan_sums_reduce_kernel, dim3(64), dim3(1024), 0, s, p.stats, nitems, chan_sums);
+        hipLaunchKernelGGL(chan_sums_reduce_kernel, dim3(64), dim3(1024), 0, s, p.stats, wgs * 4, chan_sums);
     }
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
