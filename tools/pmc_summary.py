@@ -3,7 +3,7 @@ with `--kernel-trace --output-format csv`) into profiles/*.json: mean counter va
 dispatch and kernel, in KB as rocprofv3 reports them.  bench.py reads the lattice
 kernel's entry for `roofline.traffic`.
 
-  python tools/pmc_summary.py <fetch_dir> <write_dir> <out.json> --batch 576
+  python tools/pmc_summary.py <fetch_dir> <write_dir> <out.json> --batch 768
 """
 import argparse
 import collections
