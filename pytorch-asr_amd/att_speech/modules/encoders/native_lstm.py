@@ -120,7 +120,7 @@ def _weight_gradients(dgb, xb, ybf, T, B, H, F):
             return dw_ih, [dw_hh[0], dw_hh[1]]
         _, dw_hh = _native.lstm_wgrad(dgb.view(T, B, 2, 4 * H), None, ybf)
         TB = T * B
-        g1 = _chunks(TB, 16)
+        g1 = _chunks(TB, 64)         # (64, not 16: see _weight_gradients_library)
         dw_ih = _native.sum_leading(_bmm_f32(dgb.view(g1, TB // g1, 8 * H).transpose(1, 2),
                                              xb.view(g1, TB // g1, F)))
         return dw_ih, [dw_hh[0], dw_hh[1]]
