@@ -32,11 +32,8 @@ for _ in range(3):
         y, ybf, gates, cs = _native.lstm_bidir_fwd_fused(x, wih, whh, lens)
     else:
         y, ybf, gates, cs = _native.lstm_bidir_fwd(gx, whh, lens)
-    if FUSED:
-        dg = _native.lstm_bidir_bwd_fused(dy[:, :, 0].contiguous(), whhT,
-                                          wih.view(2, 4 * H, H).transpose(1, 2).contiguous(), lens, gates, cs)[0]
-    else:
-        dg = _native.lstm_bidir_bwd(dy, whhT, lens, gates, cs)
+    # (the backward the step runs: the fused-input-gradient variant is opt-in, ASR_LSTM_FUSED_BWD)
+    dg = _native.lstm_bidir_bwd(dy, whhT, lens, gates, cs)
 torch.cuda.synchronize()
 R = int(os.environ.get('TILE_ROWS', '24'))    # batch rows per tile the host picked (24 at B=512)
 v = y[0].reshape(B, 2, H)[0::R].reshape(-1, 2, H // 64, 64)[..., :6].reshape(-1, 6)
