@@ -279,6 +279,24 @@ int asr_lstm_bidir_fwd_fused_bf16(const void *x_bf16, const void *wih_bf16,
                                   void *gates_bf16, float *csave, void *workspace,
                                   int64_t workspace_bytes, uint32_t *err_flag, void *stream);
 
+/* The same, and the direction merge of BatchRNN (encoder_utils.py:112-117: the sum of the two
+ * directions is the next layer's input) on the bf16 planes:
+ *   xsum_bf16 [T,B,H] bf16 = bf16(h_fwd) + bf16(h_rev) (the value of y_bf16[0,t+1] + y_bf16[1,t+1]
+ *             rounded to bf16, bit for bit).
+ * The recurrence runs as two launches, steps [0, ceil(T/2)) and the rest: in the second one
+ * every frame a direction reaches was written by the other direction in the first, so it adds
+ * that value to its own output on the way out — no extra pass over the planes.  For odd T the
+ * middle frame xsum[T/2] is NOT written (both directions reach it in the first launch): the
+ * caller adds that one frame.  ASR_EUNSUPPORTED as above, for T < 2 and when bit 2 of
+ * asr_lstm_fused_supported(B, H, F) is clear (H != 320; the 352-feature layer at 32-row batch
+ * tiles).  (ABI v12) */
+int asr_lstm_bidir_fwd_fused_sum_bf16(const void *x_bf16, const void *wih_bf16,
+                                      const void *whh_bf16, const int32_t *lens,
+                                      int T, int B, int H, int F, float *y, void *y_bf16,
+                                      void *gates_bf16, float *csave, void *xsum_bf16,
+                                      void *workspace, int64_t workspace_bytes,
+                                      uint32_t *err_flag, void *stream);
+
 /* Backward recurrence with the input gradient fused (replaces the `dgates·W_ih` GEMM behind
  * asr_lstm_bidir_bwd_bf16 when the layer's input size equals H):
  *   wihT_bf16 [2 dir][H (input feature)][4H] bf16 — W_ih of each direction, transposed

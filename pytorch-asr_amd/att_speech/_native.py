@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -74,6 +74,8 @@ _SIGNATURES = {
     'asr_lstm_bidir_bwd_fused_bf16': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
                                            _vp, _i64, _vp, _vp]),
     'asr_lstm_bidir_fwd_fused_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'asr_lstm_bidir_fwd_fused_sum_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                               _vp, _vp]),
     'asr_bn_act_workspace_bytes': (_i64, [_i]),
     'asr_bn_act_fwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -315,16 +317,19 @@ def lstm_bidir_fwd(gx, whh_bf16, lens, want_y=True):
     return y, ybf, gates, csave
 
 
-def lstm_fused_supported(B, H, backward=False, F=None):
+def lstm_fused_supported(B, H, backward=False, F=None, dirsum=False):
     """asr_lstm_fused_supported: can asr_lstm_bidir_fwd_fused_bf16 (bit 0) /
-    asr_lstm_bidir_bwd_fused_bf16 (bit 1) run this (batch, hidden, input size)?"""
+    asr_lstm_bidir_bwd_fused_bf16 (bit 1) / asr_lstm_bidir_fwd_fused_sum_bf16 (bit 2, `dirsum`)
+    run this (batch, hidden, input size)?"""
     F = H if F is None else F
-    return bool(lib().asr_lstm_fused_supported(int(B), int(H), int(F)) & (2 if backward else 1))
+    return bool(lib().asr_lstm_fused_supported(int(B), int(H), int(F)) & (4 if dirsum else 2 if backward else 1))
 
 
-def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True):
+def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True, want_sum=False):
     """asr_lstm_bidir_fwd_fused_bf16: x [T,B,F] bf16, wih [2*4H,F] bf16, whh [2,4H,H] bf16
-    -> the outputs of lstm_bidir_fwd, the input projection computed inside the recurrence."""
+    -> the outputs of lstm_bidir_fwd, the input projection computed inside the recurrence.
+    want_sum: also xsum [T,B,H] bf16 = ybf[0, 1:T+1] + ybf[1, 1:T+1], written by the recurrence
+    itself (asr_lstm_bidir_fwd_fused_sum_bf16); returned as a fifth value."""
     x_bf16 = _dev(x_bf16, torch.bfloat16, 'x')
     wih_bf16 = _dev(wih_bf16, torch.bfloat16, 'wih')
     whh_bf16 = _dev(whh_bf16, torch.bfloat16, 'whh')
@@ -341,6 +346,16 @@ def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True):
     csave = torch.empty((T, 2, B, H), dtype=torch.float32, device=dev)
     nbytes = L.asr_lstm_workspace_bytes(B, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if want_sum:
+        xsum = torch.empty((T, B, H), dtype=torch.bfloat16, device=dev)
+        check(L.asr_lstm_bidir_fwd_fused_sum_bf16(_p(x_bf16), _p(wih_bf16), _p(whh_bf16), _p(lens), T, B, H, F,
+                                                  _p(y), _p(ybf), _p(gates), _p(csave), _p(xsum), _p(ws), nbytes,
+                                                  _p(_lstm_err_flag(dev)), _stream()),
+              'asr_lstm_bidir_fwd_fused_sum_bf16')
+        if T % 2:           # the middle frame of an odd T: both directions reach it in the first launch
+            m = T // 2
+            torch.add(ybf[0, m + 1], ybf[1, m + 1], out=xsum[m])
+        return y, ybf, gates, csave, xsum
     check(L.asr_lstm_bidir_fwd_fused_bf16(_p(x_bf16), _p(wih_bf16), _p(whh_bf16), _p(lens), T, B, H, F,
                                           _p(y), _p(ybf), _p(gates), _p(csave), _p(ws), nbytes,
                                           _p(_lstm_err_flag(dev)), _stream()),

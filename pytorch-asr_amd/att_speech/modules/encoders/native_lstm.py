@@ -22,7 +22,7 @@ def _mm_f32(a, b):
         return torch.mm(a, b).float()
 
 
-def _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, want_y):
+def _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, want_y, want_sum=False):
     """One layer's recurrence from its bf16 input [T*B, F].  Where the library has the fused
     kernel (F == H; or H = 320, F = 352 when the fp32 outputs are not wanted) the input
     projection runs inside the persistent recurrence (asr_lstm_bidir_fwd_fused_bf16: no
@@ -34,6 +34,14 @@ def _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, want_y):
     mode = os.environ.get('ASR_LSTM_FUSED', '1')         # 0: never, inner: only F == H layers
     if (mode != '0' and (F == H or (not want_y and mode != 'inner'))
             and _native.lstm_fused_supported(B, H, F=F)):
+        # want_sum + ASR_LSTM_DIRSUM=1: the direction sum on the bf16 planes comes out of the
+        # recurrence itself (a fifth return value).  Opt-in: measured break-even at B=768 — the
+        # second launch's set-up and the per-step tile fetch cost what the saved pass over the
+        # planes (0.1 ms per layer) gains.
+        if (want_sum and T >= 2 and os.environ.get('ASR_LSTM_DIRSUM', '0') == '1'
+                and _native.lstm_fused_supported(B, H, F=F, dirsum=True)):
+            return _native.lstm_bidir_fwd_fused(xb.view(T, B, F), w_ih, whh, lens_dev, want_y=want_y,
+                                                want_sum=True)
         return _native.lstm_bidir_fwd_fused(xb.view(T, B, F), w_ih, whh, lens_dev, want_y=want_y)
     if os.environ.get('ASR_GX_FP32', '0') == '1':
         gx = _mm_f32(xb, w_ih.t()).view(T, B, 2, 4 * H)
@@ -164,10 +172,11 @@ class BiLSTMStackFunction(torch.autograd.Function):
             w_ih = torch.cat([w_ih_f, w_ih_r], 0).to(torch.bfloat16)
             whh = torch.stack([w_hh_f, w_hh_r], 0).to(torch.bfloat16).contiguous()
             last = l == n - 1
-            y, ybf, gates, csave = _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, last)
+            out = _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, last, want_sum=not last)
+            y, ybf, gates, csave = out[:4]
             saved += [xb, w_ih, whh, ybf, gates, csave]
             if not last:
-                xb = (ybf[0, 1:T + 1] + ybf[1, 1:T + 1]).view(T * B, H)
+                xb = (out[4] if len(out) > 4 else ybf[0, 1:T + 1] + ybf[1, 1:T + 1]).view(T * B, H)
         ctx.save_for_backward(lens_dev, *saved)
         ctx.n = n
         return y.sum(2)

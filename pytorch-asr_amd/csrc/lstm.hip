@@ -126,6 +126,12 @@ struct LstmFwdParams {
     u32x2 *gates;           // [T,2,B,H] records of 4 bf16 post-activation gates (saved for backward)
     float *csave;           // [T,2,B,H] cell state after the step
     int step;
+    // persistent kernel: steps [s_begin, s_end) of the T (a launch that starts past step 0
+    // picks its state up from hbuf / csave, the team counters keep counting).  xsum [T,B,H]
+    // bf16 != null: every step also writes bf16(h_own) + the OTHER direction's bf16 output of
+    // its frame — valid when that direction wrote the frame in an EARLIER launch.
+    int s_begin, s_end;
+    __bf16 *xsum;
 };
 
 // K-loop of one wave: acc += A[32 x 16*KS] * B[16*KS x 32] with both operands
@@ -573,13 +579,16 @@ struct LstmTeamCtl {
 // workgroup waits for the team's counter and waves 0-3 while the hand-off tile is in
 // flight: both windows (911 / 1036 cycles at B=512) were idle.  The sum x_t·W_ih + h·W_hh
 // is accumulated in fp32 in one MFMA chain (the bf16 rounding of `gx` is gone).
-template <int KS, int NE, int GXB, int XF>
+// SUM: the launch also writes p.xsum (see LstmFwdParams) — its own instantiation, so that the
+// other launches keep their register allocation (the XF kernels sit at 247-256 VGPRs)
+template <int KS, int NE, int GXB, int XF, int SUM = 0>
 __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, LstmTeamCtl ctl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *a_lds = reinterpret_cast<__bf16 *>(smem);                       // KS KiB
     float (*g_lds)[32][65] = reinterpret_cast<float (*)[32][65]>(smem + KS * 1024);
     __bf16 *h_lds = reinterpret_cast<__bf16 *>(smem + KS * 1024 + ASR_GLDS_BYTES);   // 4 KiB
     __bf16 *x_lds = reinterpret_cast<__bf16 *>(smem + KS * 1024 + ASR_GLDS_BYTES + 4096);   // XF KiB
+    __bf16 *o_lds = reinterpret_cast<__bf16 *>(smem + KS * 1024 + ASR_GLDS_BYTES + 4096 + XF * 1024);   // 2 x 4 KiB (SUM)
     constexpr int KX = XF > 0 ? XF : 1;
     __shared__ int dead_s;
     const int H = p.H, B = p.B, T = p.T;
@@ -669,6 +678,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         const int xr = lane & 31, b = b0 + xr < B ? b0 + xr : B - 1;
         if (xr < 8 * NE) vx = (u32)(b * (16 * KX) + 16 * wv + 8 * (lane >> 5)) * 2u;
     }
+    const int S0 = p.s_begin, S1 = p.s_end;
+    constexpr bool summ = XF && SUM;
+    const rsrc_words ybD = raw_rsrc(p.ybf, summ ? (unsigned)((u32)(2 * (T + 2)) * fyb) : 0u);
+    const __amdgpu_buffer_rsrc_t xsR = __builtin_amdgcn_make_buffer_rsrc(
+        p.xsum, 0, summ ? (int)((u32)T * fyb) : 0, 0x00020000);
     auto x_dma = [&](int tq) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -676,6 +690,23 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
                 dma16_s(xD, (unsigned)__builtin_amdgcn_readfirstlane(
                                 (int)(lds_addr(x_lds) + (unsigned)(wave + 8 * i) * 1024u)),
                         vx + (u32)i * 256u, (u32)__builtin_amdgcn_readfirstlane((int)((u32)tq * fx_frame)));
+    };
+    // SUM: the other direction's bf16 outputs of frame tq (written by an earlier launch), rows
+    // 8 wave .. + 7 of the tile x this workgroup's 64 columns: 1 KiB per wave 0..3, lane = (row,
+    // 16-byte chunk), into buffer `par` of o_lds.  Fetched one step ahead like x: these bytes come
+    // from HBM, and a DMA issued with the hand-off tile put their 2 us on every step's
+    // critical path (measured: 4.65 instead of 3.9 us per step).
+    auto o_dma = [&](int tq, int par) {
+        if (wave < 4) {
+            int ln = lane;      // (an opaque copy: hoisted out of the loop these offsets cost registers)
+            asm volatile("" : "+v"(ln));
+            const int orow = 8 * wv + (ln >> 3);
+            const u32 vo = orow < 8 * NE && b0 + orow < B
+                               ? (u32)(((b0 + orow) * H + j0) * 2 + (ln & 7) * 16) : 0x80000000u;
+            dma16_s(ybD, (unsigned)__builtin_amdgcn_readfirstlane(
+                             (int)(lds_addr(o_lds) + (unsigned)par * 4096u + (unsigned)wv * 1024u)), vo,
+                    (u32)__builtin_amdgcn_readfirstlane((int)((u32)((1 - dir) * (T + 2) + tq + 1) * fyb)));
+        }
     };
     // y == null: zero records, every fp32 output store is dropped by the bounds check
     const __amdgpu_buffer_rsrc_t yR = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y ? (int)((u32)T * fy) : 0, 0x00020000);
@@ -694,12 +725,35 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     // (behind the hand-off tile in the wave's in-order vmcnt queue, never in
     // front of the team poll); the outputs nobody inside the launch reads are
     // stored after the team signal, under the hand-off latency.
+    if (S0 > 0) {
+        // pick the state up where the previous launch left it: c_{t-1} from csave, this
+        // workgroup's own part of h_{t-1} from the hand-off buffer (the same bytes h_lds held)
+        const int tp = dir == 0 ? S0 - 1 : T - S0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            c[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                csR, inb[e] ? l4 : OOBV, (u32)tp * fcs + scs[e], 0));
+        __syncthreads();                // the zero fill of h_lds above
+        if (tid < 256) {
+            const unsigned off = (unsigned)(((((size_t)(S0 & 1) * 2 + dir) * Bp * H) +
+                                             ((size_t)btile * KS + 4 * jt + (tid >> 6)) * 512 + (tid & 63) * 8) * 2);
+            reinterpret_cast<u32x4 *>(h_lds)[tid] = __builtin_amdgcn_raw_buffer_load_b128(
+                hres, (tid & 31) < 8 * NE ? off : 0xFFFFFFFFu, 0, ASR_SC1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int row = e * 8 + wave;
+            hq[e] = h_lds[(((col >> 4) * 64) + row + 32 * ((col >> 3) & 1)) * 8 + (col & 7)];
+        }
+    }
     float pgx[XF ? 1 : NE][4];
     {
-        const int t0 = dir == 0 ? 0 : T - 1;
+        const int t0 = dir == 0 ? S0 : T - 1 - S0;
         if constexpr (XF) {
             __syncthreads();            // the zero fill above
             x_dma(t0);
+            if constexpr (summ) o_dma(t0, S0 & 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         } else {
@@ -726,7 +780,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
     float soh[NE] = {}, sc[NE] = {};
     __bf16 shq[NE] = {};                 // NOY: the bf16 output of the step (0 on padding frames)
     bool sact[NE] = {};
-    int st = 0;
+    int st = 0, st_par = 0;
     // live == false (the first step has nothing to store yet): every offset out of range,
     // so the call has the same VMEM count on every step (counted vmcnt waits around it)
     auto bulk_store = [&](bool live) {
@@ -744,6 +798,21 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
                                                   on ? l4 : OOBV, ust * fcs + scs[e], 0);
             __builtin_amdgcn_raw_buffer_store_b64(sog[e], gR,
                                                   on && sact[e] ? l4 * 2u : OOBV, ust * fg + scs[e] * 2u, 0);
+        }
+    };
+    // SUM: own output + the other direction's (buffer st_par of o_lds), issued BEHIND the team
+    // signal: its LDS reads would otherwise sit between the hand-off store and the signal
+    auto sum_store = [&]() {
+        const u32 ust = (u32)st;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const bool on = inb[e];
+            int cl = col;
+            asm volatile("" : "+v"(cl));
+            const __bf16 xs = (__bf16)((float)shq[e] + (float)o_lds[st_par * 2048 + (e * 8 + wave) * 64 + cl]);
+            __builtin_amdgcn_raw_buffer_store_b16(
+                (short)__builtin_bit_cast(unsigned short, xs), xsR, on ? l2 : OOBV,
+                ust * fyb + (u32)__builtin_amdgcn_readfirstlane(((b0 + e * 8 + wv) * H + j0) * 2), 0);
         }
     };
 
@@ -764,7 +833,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         for (int e = 0; e < NE; ++e) asm volatile("" : "+v"(len[e]));
     }
     PSTAMP_DECL;
-    for (int step = 0; step < T; ++step) {
+    for (int step = S0; step < S1; ++step) {
         const int t = dir == 0 ? step : T - 1 - step;
         if constexpr (XF) if (wave >= 4) x_mfma();          // under the team wait
         if (step > 0 && tid == 0 && !dead_s) {
@@ -833,6 +902,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
                 // (32-row tiles keep two weight fragments in scratch; their reloads inside the
                 // MFMA loop would wait for this DMA: issued behind the loop there)
                 if constexpr (NE < 4) x_dma(tn);
+                if constexpr (summ) o_dma(tn, (step + 1) & 1);      // (read in the cell phase of step + 1)
             } else {
 #pragma unroll
                 for (int e = 0; e < NE; ++e)
@@ -865,6 +935,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         PSTAMP(2);
         const bool dead = dead_s != 0;
         st = t;
+        st_par = step & 1;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int row = e * 8 + wave;
@@ -906,6 +977,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         __syncthreads();
         PSTAMP(4);
         if (tid == 0) __hip_atomic_fetch_add(myctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (summ) sum_store();
         if constexpr (!XF) {
 #pragma unroll
             for (int e = 0; e < NE; ++e)
@@ -1613,7 +1685,7 @@ extern "C" int64_t asr_lstm_workspace_bytes(int B, int H) {
 namespace {
 int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *wih_bf16, int F,
                   const void *whh_bf16, const int32_t *lens, int T, int B, int H,
-                  float *y, void *y_bf16, void *gates_bf16, float *csave,
+                  float *y, void *y_bf16, void *gates_bf16, float *csave, void *xsum_bf16,
                   void *workspace, int64_t workspace_bytes, uint32_t *err_flag, void *stream);
 }
 
@@ -1625,7 +1697,7 @@ extern "C" int asr_lstm_bidir_fwd_bf16(const void *gx, int gx_bf16, const void *
                                        uint32_t *err_flag, void *stream) {
     if (!gx) return ASR_EINVAL;
     return lstm_fwd_impl(gx, gx_bf16, nullptr, nullptr, 0, whh_bf16, lens, T, B, H, y, y_bf16,
-                         gates_bf16, csave, workspace, workspace_bytes, err_flag, stream);
+                         gates_bf16, csave, nullptr, workspace, workspace_bytes, err_flag, stream);
 }
 
 extern "C" int asr_lstm_bidir_fwd_fused_bf16(const void *x_bf16, const void *wih_bf16,
@@ -1636,7 +1708,26 @@ extern "C" int asr_lstm_bidir_fwd_fused_bf16(const void *x_bf16, const void *wih
                                              void *stream) {
     if (!x_bf16 || !wih_bf16) return ASR_EINVAL;
     return lstm_fwd_impl(nullptr, 1, x_bf16, wih_bf16, F, whh_bf16, lens, T, B, H, y, y_bf16,
-                         gates_bf16, csave, workspace, workspace_bytes, err_flag, stream);
+                         gates_bf16, csave, nullptr, workspace, workspace_bytes, err_flag, stream);
+}
+
+// ... and xsum [T,B,H] bf16 = bf16(h_fwd) + bf16(h_rev), the next layer's input (BatchRNN's
+// direction merge, encoder_utils.py:112-117, on the bf16 planes): the recurrence runs as TWO
+// launches, steps [0, ceil(T/2)) and the rest; in the second every frame a direction reaches
+// was written by the other one in the first, so it adds that value to its own output — no
+// separate pass over the planes (0.1 ms per layer at B=768), no cross-direction hand-shake.
+// For odd T the middle frame is reached by both directions in the first launch: it is left
+// to the caller (xsum[T/2] is not written).
+extern "C" int asr_lstm_bidir_fwd_fused_sum_bf16(const void *x_bf16, const void *wih_bf16,
+                                                 const void *whh_bf16, const int32_t *lens,
+                                                 int T, int B, int H, int F, float *y, void *y_bf16,
+                                                 void *gates_bf16, float *csave, void *xsum_bf16,
+                                                 void *workspace, int64_t workspace_bytes,
+                                                 uint32_t *err_flag, void *stream) {
+    if (!x_bf16 || !wih_bf16 || !xsum_bf16) return ASR_EINVAL;
+    if (T < 2) return ASR_EUNSUPPORTED;
+    return lstm_fwd_impl(nullptr, 1, x_bf16, wih_bf16, F, whh_bf16, lens, T, B, H, y, y_bf16,
+                         gates_bf16, csave, xsum_bf16, workspace, workspace_bytes, err_flag, stream);
 }
 
 extern "C" int asr_lstm_fused_supported(int B, int H, int F) {
@@ -1644,20 +1735,24 @@ extern "C" int asr_lstm_fused_supported(int B, int H, int F) {
     if (H != 64 && H != 128 && H != 256 && H != 320) return 0;
     // input size: the hidden size, or (H = 320) the 352 features of the conv front-end —
     // forward only
-    if (F != H) return (H == 320 && F == 352 && cu_count() >= 2 * (H / 64)) ? 1 : 0;
+    // bit 2: asr_lstm_bidir_fwd_fused_sum_bf16 (H = 320; not the 352-feature layer at 32-row tiles)
+    if (F != H)
+        return (H == 320 && F == 352 && cu_count() >= 2 * (H / 64))
+                   ? 1 | (pick_tile_rows(B, H / 64, cu_count()) < 4 ? 4 : 0) : 0;
     const int cus = cu_count(), njt = H / 64;
     if (cus < 2 * njt) return 0;
     // bit 0: forward (input projection); bit 1: backward (input gradient) — its kernel has no
     // LDS left for 32-row batch tiles, i.e. the batch must fit one launch of 16/24-row tiles
-    return 1 | (pick_tile_rows(B, njt, cus) < 4 ? 2 : 0);
+    return 1 | (pick_tile_rows(B, njt, cus) < 4 ? 2 : 0) | (H == 320 ? 4 : 0);
 }
 
 namespace {
 int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *wih_bf16, int F,
                   const void *whh_bf16, const int32_t *lens, int T, int B, int H,
-                  float *y, void *y_bf16, void *gates_bf16, float *csave,
+                  float *y, void *y_bf16, void *gates_bf16, float *csave, void *xsum_bf16,
                   void *workspace, int64_t workspace_bytes, uint32_t *err_flag, void *stream) {
     const bool fused = x_bf16 != nullptr;
+    if (xsum_bf16 && !fused) return ASR_EINVAL;
     if (T < 0 || B <= 0 || H <= 0 || (H % 32) != 0) return ASR_EINVAL;
     if (T == 0) return ASR_OK;
     if (!whh_bf16 || !lens || !y_bf16 || !gates_bf16 || !csave || !workspace)
@@ -1677,6 +1772,7 @@ int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *w
     p.hbuf = (__bf16 *)workspace;
     p.cbuf = (float *)((char *)workspace + hbytes);
     p.y = y; p.ybf = (__bf16 *)y_bf16; p.gates = (u32x2 *)gates_bf16; p.csave = csave;
+    p.step = 0; p.s_begin = 0; p.s_end = T; p.xsum = nullptr;
     ZeroList zl;
     zl.add(workspace, hbytes + cbytes);
     // the two pad frames of every direction of y_bf16
@@ -1711,12 +1807,29 @@ int lstm_fwd_impl(const void *gx, int gx_bf16, const void *x_bf16, const void *w
             pk[0] = lstm_fwd_persist_kernel<20, 2, 1, 22>; pk[1] = lstm_fwd_persist_kernel<20, 3, 1, 22>;
             pk[2] = lstm_fwd_persist_kernel<20, 4, 1, 22>;
         }
+        // the second launch of the direction-sum variant (H = 320 only; the 32-row tile kernel
+        // of the 352-feature layer has no register left for it: that layer's caller adds)
+        void (*pks[3])(LstmFwdParams, LstmTeamCtl) = {nullptr, nullptr, nullptr};
+        if (H == 320 && fused && F == H) {
+            pks[0] = lstm_fwd_persist_kernel<20, 2, 1, 20, 1>; pks[1] = lstm_fwd_persist_kernel<20, 3, 1, 20, 1>;
+            pks[2] = lstm_fwd_persist_kernel<20, 4, 1, 20, 1>;
+        }
+        if (H == 320 && fused && F == 352) {
+            pks[0] = lstm_fwd_persist_kernel<20, 2, 1, 22, 1>; pks[1] = lstm_fwd_persist_kernel<20, 3, 1, 22, 1>;
+        }
+        if (xsum_bf16 && !pks[pick_tile_rows(B, H / 64, cu_count()) - 2]) return ASR_EUNSUPPORTED;
         // the persistent kernel addresses gx / y / gates / ... with 32-bit byte offsets
         const bool fits32 = (uint64_t)T * B * 8 * H * 4 < (1ull << 32) &&
                             (uint64_t)2 * (T + 2) * B * H * 2 < (1ull << 32);
-        if (fits32 && pk[2] && launch_persist(pk, p, B, H, (size_t)(H / 16) * 1024 + (fused ? (size_t)(F / 16) * 1024 : 0) + ASR_GLDS_BYTES + 4096,
-                                 ctl_words, err_flag, s))
+        const size_t lds_need = (size_t)(H / 16) * 1024 + (fused ? (size_t)(F / 16) * 1024 + 8192 : 0) + ASR_GLDS_BYTES + 4096;
+        if (xsum_bf16) p.s_end = (T + 1) / 2;
+        if (fits32 && pk[2] && launch_persist(pk, p, B, H, lds_need, ctl_words, err_flag, s)) {
+            if (xsum_bf16) {        // the second half: same counters, state from hbuf / csave
+                p.s_begin = p.s_end; p.s_end = T; p.xsum = (__bf16 *)xsum_bf16;
+                if (!launch_persist(pks, p, B, H, lds_need, ctl_words, err_flag, s)) return ASR_ELAUNCH;
+            }
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+        }
     }
     if (fused) return ASR_EUNSUPPORTED;
     // one launch per step.  64-row tiles (bt = 2) halve the W_hh re-reads but were

@@ -142,6 +142,46 @@ def test_fused_input_projection_first_layer_shape(T, B, reps):
     _fused_projection_case(T, B, 320, 352, reps)
 
 
+@pytest.mark.parametrize('T,B,F', [(2, 3, 320), (23, 7, 320), (24, 40, 320), (151, 96, 320), (334, 576, 320),
+                                   (334, 768, 320), (40, 900, 320), (23, 7, 352), (150, 96, 352), (334, 576, 352)])
+def test_direction_sum_inside_the_recurrence(T, B, F):
+    """asr_lstm_bidir_fwd_fused_sum_bf16: the recurrence as two launches (steps [0, ceil(T/2)) and
+    the rest, the second picking its state up from the hand-off buffer / csave), the second
+    adding the other direction's bf16 output of each frame to its own.  Every output must be
+    bit-identical to the single launch (same arithmetic; a wrong restored state, a stale tile
+    or a missed frame changes bits), xsum bit-identical to the add over the two planes; odd
+    and even T, ragged lengths, 16/24/32-row tiles, a batch that needs several launches."""
+    from att_speech import _native
+    dev = torch.device('cuda:0')
+    H = 320
+    if not _native.lstm_fused_supported(B, H, F=F, dirsum=True):
+        pytest.skip('no direction-sum kernel for this (batch, input size)')
+    g = torch.Generator().manual_seed(T * 13 + B + F)
+    lens = torch.randint(1, T + 1, (B,), generator=g).sort(descending=True)[0]
+    lens[0] = T
+    x = torch.randn(T, B, F, generator=g).to(dev, torch.bfloat16)
+    wih = (torch.randn(8 * H, F, generator=g) * (1.0 / F ** 0.5)).to(dev, torch.bfloat16)
+    whh = (torch.randn(2, 4 * H, H, generator=g) * (1.0 / H ** 0.5)).to(dev, torch.bfloat16)
+    lens_d = lens.to(dev, torch.int32)
+    want_y = F == H
+    one = _native.lstm_bidir_fwd_fused(x, wih, whh, lens_d, want_y=want_y)
+    act = (torch.arange(T)[:, None] < lens[None, :]).to(dev)
+    for _ in range(2):
+        two = _native.lstm_bidir_fwd_fused(x, wih, whh, lens_d, want_y=want_y, want_sum=True)
+        torch.cuda.synchronize()
+        _native.lstm_check_errors()
+        for name, a, b in zip(('y', 'y_bf16', 'gates', 'csave'), two, one):
+            if a is None:
+                continue
+            if name == 'gates':         # records of padding frames are never written
+                m = act[:, None, :, None, None].expand_as(a)
+                a, b = a[m], b[m]
+            assert torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32),
+                               b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32)), name
+        want = one[1][0, 1:T + 1] + one[1][1, 1:T + 1]
+        assert torch.equal(two[4].view(torch.int16), want.view(torch.int16))
+
+
 def _fused_projection_case(T, B, H, F, reps):
     """asr_lstm_bidir_fwd_fused_bf16 (x_t·W_ih inside the persistent kernel, the tile brought
     in by LDS-DMA under the hand-off waits) against the fp32 product of the same bf16
