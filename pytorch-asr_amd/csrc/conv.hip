@@ -862,17 +862,25 @@ struct Conv1Params {
     int B, T, F, To, Fo;
 };
 
-// window image of input rows t0-6 .. t0-6+nrows-1: [nrows][Fo] x 8 bf16
+// window image of input rows t0-6 .. t0-6+nrows-1: [nrows][Fo] x 8 bf16 (a window's 8 samples
+// are four 8-byte loads: 2 fo + 7 <= F - 1 by the definition of Fo; the row index by
+// multiplication: i / Fo = (i * fmagic) >> 20 for i * Fo < 2^20)
 __device__ __forceinline__ void conv1_stage_windows(const Conv1Params &p, int b, int t0, int nrows,
                                                     char *wimg, int tid, int nt) {
     const float *xb = p.x + (size_t)b * p.T * p.F;
+    const unsigned fmagic = (1u << 20) / (unsigned)p.Fo + 1u;
     for (int i = tid; i < nrows * p.Fo; i += nt) {
-        const int row = i / p.Fo, fo = i - row * p.Fo, t = t0 - 6 + row;
-        bf16x8 v;
+        const unsigned row = ((unsigned)i * fmagic) >> 20, fo = (unsigned)i - row * (unsigned)p.Fo;
+        const int t = t0 - 6 + (int)row;
+        bf16x8 v = {};
+        if (t >= 0 && t < p.T) {
+            const float2 *src = reinterpret_cast<const float2 *>(xb + (size_t)t * p.F + 2 * fo);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int f = 2 * fo + j;
-            v[j] = (t >= 0 && t < p.T && f < p.F) ? (__bf16)xb[(size_t)t * p.F + f] : (__bf16)0.f;
+            for (int j = 0; j < 4; ++j) {
+                const float2 f2 = src[j];
+                v[2 * j] = (__bf16)f2.x;
+                v[2 * j + 1] = (__bf16)f2.y;
+            }
         }
         *reinterpret_cast<bf16x8 *>(wimg + (size_t)i * 16) = v;
     }
@@ -891,23 +899,25 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Params p) {
     for (int s = 0; s < 4; ++s) bf[s] = reinterpret_cast<const bf16x8 *>(p.wpack)[s * 64 + lane];
     conv1_stage_windows(p, b, t0, C1_ROWS + 8, wimg, tid, 256);   // rows past the 7th tap: finite
     __syncthreads();
+    const unsigned fmagic = (1u << 20) / (unsigned)Fo + 1u;
     for (int tile = wave; tile < ntiles; tile += 4) {
         int m = 32 * tile + (lane & 31);
         if (m >= npix) m = npix - 1;
-        const int r = m / Fo, fo = m - r * Fo;
-        const char *base = wimg + (size_t)((r + (lane >> 5)) * Fo + fo) * 16;
-        f32x16 acc;
+        const unsigned r = ((unsigned)m * fmagic) >> 20, fo = (unsigned)m - r * (unsigned)Fo;
+        const char *base = wimg + (size_t)((r + (unsigned)(lane >> 5)) * (unsigned)Fo + fo) * 16;
+        bf16x8 a[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const bf16x8 *>(base + (size_t)(2 * s * Fo) * 16);
+        // operands swapped (weights as the MFMA's A): a lane ends up with 4 consecutive co of
+        // pixel lane & 31 per register quad — 8-byte LDS writes instead of 2-byte ones
+        f32x16 acc = {};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(base + (size_t)(2 * s * Fo) * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[s], acc, 0, 0, 0);
-        }
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s], a[s], acc, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int mm = 32 * tile + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
-            oimg[mm * CH + (lane & 31)] = (__bf16)acc[j];
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 o4 = {(__bf16)acc[4 * g], (__bf16)acc[4 * g + 1], (__bf16)acc[4 * g + 2], (__bf16)acc[4 * g + 3]};
+            *reinterpret_cast<bf16x4 *>(reinterpret_cast<char *>(oimg) + (size_t)(32 * tile + (lane & 31)) * 64 +
+                                        16 * g + 8 * (lane >> 5)) = o4;
         }
     }
     __syncthreads();
