@@ -738,6 +738,8 @@ __global__ __launch_bounds__(WGRAD_NT) void conv7x7c32_wgrad_s3_kernel(ConvWgrad
     const int nchunks = p.B * chunks_per_utt;
     const int nx = xrows * W * 4, nd = rows * Wd * 4;
     u32x4 sx[NX_MAX], sd[ND_MAX];
+    // pix / W, pix / Wd by multiplication (pix < 2^12, divisors <= 64: exact)
+    const unsigned wmagic = (1u << 20) / (unsigned)W + 1u, dmagic = (1u << 20) / (unsigned)Wd + 1u;
     // global -> registers: x rows 3 ho0 .. 3 ho0 + xrows - 1 (zeros past H), dy rows ho0 .. (zero
     // pixels up to Wd and past Ho)
     auto fetch = [&](int c) {
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(WGRAD_NT) void conv7x7c32_wgrad_s3_kernel(ConvWgrad
 #pragma unroll
         for (int k = 0; k < NX_MAX; ++k) {
             const int i = tid + k * WGRAD_NT;
-            const int pix = i >> 2, part = i & 3, row = pix / W;
+            const int pix = i >> 2, part = i & 3, row = (int)(((unsigned)pix * wmagic) >> 20);
             u32x4 v = {0u, 0u, 0u, 0u};
             if (i < nx && 3 * ho0 + row < p.H)
                 v = *reinterpret_cast<const u32x4 *>(xb + ((size_t)(3 * ho0) * W + pix) * 64 + part * 16);
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(WGRAD_NT) void conv7x7c32_wgrad_s3_kernel(ConvWgrad
 #pragma unroll
         for (int k = 0; k < ND_MAX; ++k) {
             const int i = tid + k * WGRAD_NT;
-            const int pix = i >> 2, part = i & 3, row = pix / Wd, wo = pix - row * Wd;
+            const int pix = i >> 2, part = i & 3, row = (int)(((unsigned)pix * dmagic) >> 20), wo = pix - row * Wd;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (i < nd && ho0 + row < p.Ho && wo < Wo)
                 v = *reinterpret_cast<const u32x4 *>(yb + ((size_t)(ho0 + row) * Wo + wo) * 64 + part * 16);
