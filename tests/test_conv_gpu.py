@@ -81,7 +81,9 @@ def test_conv_weight_gradient_matches_conv2d(B, H, W):
     assert float((got - want).abs().max()) <= 2e-3 * scale      # fp32 accumulation of exact products
 
 
-@pytest.mark.parametrize('B,T,F', [(2, 50, 40), (1, 1000, 40), (3, 33, 81), (2, 5, 9)])
+# (F = 53 / 81: the weight-gradient kernel's other prefetch-register sizes; 40 x 1000 x 40: more
+#  chunks than persistent workgroups)
+@pytest.mark.parametrize('B,T,F', [(2, 50, 40), (1, 1000, 40), (3, 33, 81), (2, 5, 9), (2, 30, 53), (40, 1000, 40)])
 def test_first_convolution_forward_and_weight_gradient(B, T, F):
     """Conv2d(1, 32, 7x7, stride (1, 2), padding (6, 0)) on the raw features"""
     from att_speech import _native
