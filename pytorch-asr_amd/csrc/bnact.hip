@@ -497,6 +497,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_nhwc8_kernel(BnParamsN p, cons
 // these move rows of y / dy as whole contiguous 16- or 8-byte pieces and transpose through
 // an fp32 LDS tile of TMR rows (bank pattern: 4 W cg + w over a half-wave = 32 distinct
 // banks for W odd).  Same arithmetic, same accumulation order per thread.
+// x / d for x < 2^20, d < 2^10 by multiplication (m = 2^32 / d + 1; d = 1: x itself).  The tile
+// loops below used run-time `/`: 3-4 integer divisions (one of them 64-bit) per 8- or 16-byte
+// piece — 40-100 VALU instructions each — held these kernels at 2.5 TB/s.
+struct FastDiv {
+    unsigned m, d;
+    __device__ __forceinline__ explicit FastDiv(int dd) : m((unsigned)((1ull << 32) / (unsigned)dd) + 1u), d((unsigned)dd) {}
+    __device__ __forceinline__ int operator()(int x) const { return d == 1u ? x : (int)__umulhi((unsigned)x, m); }
+};
+
 template <typename T>
 __device__ __forceinline__ void tm_row_to_lds(const T *row, float *tile, int CW, int it) {
     const F4 v = load4(row + 4 * it);
@@ -516,10 +525,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_nhwc_tm_kernel(BnParamsN p, Ou
         sh[i] = p.beta[c0 + i] - (p.mean[c0 + i] - (p.shift ? p.shift[c0 + i] : 0.f)) * sc[i];
     }
     const int64_t nrows = p.P / W;
+    const FastDiv dCG(CG), dW(W), dQ(Q);
     for (int64_t r0 = (int64_t)blockIdx.x * TMR; r0 < nrows; r0 += (int64_t)gridDim.x * TMR) {
         const int nr = nrows - r0 < TMR ? (int)(nrows - r0) : TMR;
+        const int b0 = (int)(r0 / p.H), h0 = (int)(r0 - (int64_t)b0 * p.H);     // (uniform: once per tile)
         for (int it = threadIdx.x; it < nr * W * CG; it += 256) {
-            const int j = it / CG, row = j / W, w = j - row * W;      // pixel j of the tile
+            const int j = dCG(it), row = dW(j), w = j - row * W;      // pixel j of the tile
             const F4 v = load4(px + (r0 * W + j) * C + c0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -527,9 +538,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_nhwc_tm_kernel(BnParamsN p, Ou
         }
         __syncthreads();
         for (int it = threadIdx.x; it < nr * Q; it += 256) {
-            const int row = it / Q, k = it - row * Q;
-            const int64_t r = r0 + row;
-            const int b = (int)(r / p.H), h = (int)(r - (int64_t)b * p.H);
+            const int row = dQ(it), k = it - row * Q;
+            int h = h0 + row, b = b0;
+            while (h >= p.H) { h -= p.H; ++b; }                       // (a tile spans few rows)
             const float4 t = *reinterpret_cast<const float4 *>(tile + row * CW + 4 * k);
             store4(out + ((size_t)h * p.B + b) * CW + 4 * k, F4{{t.x, t.y, t.z, t.w}});
         }
@@ -554,17 +565,19 @@ __global__ __launch_bounds__(256) void bn_act_bwd_nhwc_tm_kernel(BnParamsN p, co
         k2[i] = MODE == 1 && training ? (float)(sums[2 * (c0 + i) + 1] / n) : 0.f;
     }
     const int64_t nrows = p.P / W;
+    const FastDiv dCG(CG), dW(W), dQ(Q);
     for (int64_t r0 = (int64_t)blockIdx.x * TMR; r0 < nrows; r0 += (int64_t)gridDim.x * TMR) {
         const int nr = nrows - r0 < TMR ? (int)(nrows - r0) : TMR;
+        const int b0 = (int)(r0 / p.H), h0 = (int)(r0 - (int64_t)b0 * p.H);     // (uniform: once per tile)
         for (int it = threadIdx.x; it < nr * Q; it += 256) {
-            const int row = it / Q, k = it - row * Q;
-            const int64_t r = r0 + row;
-            const int b = (int)(r / p.H), h = (int)(r - (int64_t)b * p.H);
+            const int row = dQ(it), k = it - row * Q;
+            int h = h0 + row, b = b0;
+            while (h >= p.H) { h -= p.H; ++b; }                       // (a tile spans few rows)
             tm_row_to_lds(dy + ((size_t)h * p.B + b) * CW, tile + row * CW, CW, k);
         }
         __syncthreads();
         for (int it = threadIdx.x; it < nr * W * CG; it += 256) {
-            const int j = it / CG, row = j / W, w = j - row * W;
+            const int j = dCG(it), row = dW(j), w = j - row * W;
             const F4 v = load4(px + (r0 * W + j) * C + c0);
             F4 o;
 #pragma unroll
