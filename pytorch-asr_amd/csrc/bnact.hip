@@ -613,6 +613,16 @@ __global__ void zero_doubles_kernel(double *p, int n) {
     if (i < n) p[i] = 0.0;
 }
 
+// rows of a time-major tile (fp32, cw floats per row).  8, not as many as fit: with 32 rows
+// (45 KB of LDS at cw = 352) three workgroups shared a CU and the load -> transpose -> store
+// phases of a tile had nothing to overlap with: 130 / 216 / 214 us forward / backward reduce /
+// backward apply at B=768; at 8 rows 74 / 169 / 111 (16 rows: 95 / 186 / 157, 4: 90 / 188 / 137).
+inline int tm_rows(int cw) {
+    if (cw <= 0) return 0;
+    const int fit = 48 * 1024 / (cw * 4);
+    return fit < 8 ? fit : 8;
+}
+
 inline bool bad_shape(int B, int C, int H, int W) {
     return B <= 0 || C <= 0 || H <= 0 || W <= 0 || C > 65535 || B > 65535 ||
            (int64_t)H * W > 0x7fffffff;
@@ -669,7 +679,7 @@ extern "C" int asr_bn_act_fwd_f32(const void *x, int x_bf16, const float *conv_b
         q.x = x; q.P = P; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma; q.beta = beta;
         q.mean = save_mean; q.invstd = save_invstd; q.shift = conv_bias; q.lo = lo; q.hi = hi;
         // time-major output through the LDS transpose when a row of it is whole 16-byte pieces
-        const int cw = C * W, tmr = cw > 0 ? (48 * 1024 / (cw * 4) < 32 ? 48 * 1024 / (cw * 4) : 32) : 0;
+        const int cw = C * W, tmr = tm_rows(cw);
         if (out_time_major && cw % 8 == 0 && tmr >= 1) {
             const int64_t rows = (int64_t)B * H;
             const int g2 = (int)((rows + tmr - 1) / tmr < 2048 ? (rows + tmr - 1) / tmr : 2048);
@@ -736,7 +746,7 @@ extern "C" int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_b
         q.x = x; q.P = (int64_t)B * HW; q.B = B; q.C = C; q.H = H; q.W = W; q.gamma = gamma;
         q.beta = beta; q.mean = save_mean; q.invstd = save_invstd; q.shift = conv_bias; q.lo = lo; q.hi = hi;
         const int nwg = (int)(q.P / 64 < 4096 ? (q.P / 64 > 0 ? q.P / 64 : 1) : 4096);
-        const int cw = C * W, tmr = cw > 0 ? (48 * 1024 / (cw * 4) < 32 ? 48 * 1024 / (cw * 4) : 32) : 0;
+        const int cw = C * W, tmr = tm_rows(cw);
         if (dy_time_major && cw % 8 == 0 && tmr >= 1) {
             const int64_t rows = (int64_t)B * H;
             const int g2 = (int)((rows + tmr - 1) / tmr < 2048 ? (rows + tmr - 1) / tmr : 2048);
