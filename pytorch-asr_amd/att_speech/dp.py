@@ -33,6 +33,30 @@ class FlatGradBucket(object):
         # keeps the views alive (optimizer.zero_grad(set_to_none=True) would drop them)
         self.flat.zero_()
 
+    def detach_grads(self):
+        """Before backward: drop the .grad views so that autograd hands every parameter its
+        gradient as a tensor of its own instead of adding it into a zeroed view — one small
+        `add` kernel per parameter (27 per step for the WSJ model) — and `gather` copies them
+        into the flat buffer with one multi-tensor launch."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """After backward: the gradients into the flat buffer (one `_foreach_copy_`), .grad = the
+        views again; parameters that received no gradient read as zero."""
+        views, grads, off = [], [], 0
+        for p in self.params:
+            view = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                views.append(view)
+                grads.append(p.grad.detach())
+            p.grad = view
+        if views:
+            torch._foreach_copy_(views, grads)
+
     def check_views(self):
         """backward accumulates in place into .grad when it exists; re-attach a
         view if something replaced it."""
@@ -104,11 +128,12 @@ def train_step(model, optimizer, batch_args, hooks=(), bucket=None, current_iter
         skip = skip or bool(h.pre_backward(model=model, optimizer=optimizer,
                                            current_iteration=current_iteration, loss=loss))
     if bucket is not None:
-        bucket.zero_()
+        bucket.detach_grads()
     else:
         optimizer.zero_grad()
     loss.backward()
     if bucket is not None:
+        bucket.gather()
         bucket.all_reduce_sum(group)
     for h in hooks:
         if hasattr(h, 'bucket'):

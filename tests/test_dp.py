@@ -219,3 +219,29 @@ def test_speech_model_train_step_two_ranks():
         assert abs(clipped_norm - 1.0) <= 1e-3
         want = flat * (1.0 / (total + 1e-6))
         torch.testing.assert_close(torch.from_numpy(got), want, rtol=2e-3, atol=2e-5)
+
+def test_bucket_gather_equals_in_place_accumulation():
+    """FlatGradBucket.detach_grads / gather (gradients copied into the flat buffer with one
+    multi-tensor launch) against backward accumulating into zeroed views; a parameter that
+    receives no gradient reads as zero."""
+    import torch
+    from att_speech.dp import FlatGradBucket
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+    unused = torch.nn.Parameter(torch.ones(4))
+    params = list(net.parameters()) + [unused]
+    x = torch.randn(6, 5)
+    bucket = FlatGradBucket(params)
+    bucket.zero_()
+    net(x).pow(2).sum().backward()
+    want = bucket.flat.clone()
+    bucket.flat.fill_(123.0)                 # stale contents must not survive
+    bucket.detach_grads()
+    net(x).pow(2).sum().backward()
+    bucket.gather()
+    assert torch.equal(bucket.flat, want)
+    off = 0
+    for p in params:
+        assert p.grad.data_ptr() == bucket.flat[off:off + p.numel()].data_ptr()
+        off += p.numel()
+    assert float(unused.grad.abs().sum()) == 0.0
