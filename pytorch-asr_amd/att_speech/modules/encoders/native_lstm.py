@@ -166,11 +166,22 @@ class BiLSTMStackFunction(torch.autograd.Function):
         n = len(weights) // 4
         saved, xb = [], x.reshape(T * B, F).to(torch.bfloat16)
         ctx.x_bf16 = x.dtype == torch.bfloat16        # then the input gradient is bf16 too
+        # bf16 operands of all layers, the two directions stacked: ONE multi-tensor copy into
+        # views of the stacked buffers (cat + cast per matrix were 16 small launches per step)
+        w_ihs, whhs, dst, src = [], [], [], []
         for l in range(n):
             w_ih_f, w_hh_f, w_ih_r, w_hh_r = weights[4 * l:4 * l + 4]
-            H = w_hh_f.shape[1]
-            w_ih = torch.cat([w_ih_f, w_ih_r], 0).to(torch.bfloat16)
-            whh = torch.stack([w_hh_f, w_hh_r], 0).to(torch.bfloat16).contiguous()
+            H4, Fl = w_ih_f.shape
+            w_ih = torch.empty((2 * H4, Fl), dtype=torch.bfloat16, device=x.device)
+            whh = torch.empty((2, H4, w_hh_f.shape[1]), dtype=torch.bfloat16, device=x.device)
+            dst += [w_ih[:H4], w_ih[H4:], whh[0], whh[1]]
+            src += [w_ih_f.detach(), w_ih_r.detach(), w_hh_f.detach(), w_hh_r.detach()]
+            w_ihs.append(w_ih)
+            whhs.append(whh)
+        torch._foreach_copy_(dst, src)
+        for l in range(n):
+            w_ih, whh = w_ihs[l], whhs[l]
+            H = whh.shape[2]
             last = l == n - 1
             out = _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, last, want_sum=not last)
             y, ybf, gates, csave = out[:4]
