@@ -88,6 +88,36 @@ __device__ __forceinline__ void lstm_cell_fwd(const float pre[4], float cprev, f
     h = gate[3] * tanhf_(c);
 }
 
+// Two elements at a time: the multiplies and adds around the transcendentals as packed fp32
+// operations (v_pk_mul_f32 / v_pk_add_f32), half the instructions; the same IEEE operations in
+// the same order per element, so the results are bit for bit those of lstm_cell_fwd.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 sigmoid2_(f32x2 x) {
+#pragma clang fp contract(off)
+    const f32x2 t = x * -1.4426950408889634f;
+    f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    e = e + 1.f;
+    return f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+}
+__device__ __forceinline__ f32x2 tanh2_(f32x2 x) {
+#pragma clang fp contract(off)
+    const f32x2 t = x * -2.8853900817779268f;
+    f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    e = e + 1.f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    return r * 2.f - 1.f;
+}
+__device__ __forceinline__ void lstm_cell_fwd2(const f32x2 pre[4], f32x2 cprev, f32x2 gate[4],
+                                               f32x2 &c, f32x2 &h) {
+#pragma clang fp contract(off)
+    gate[0] = sigmoid2_(pre[0]);
+    gate[1] = sigmoid2_(pre[1]);
+    gate[2] = tanh2_(pre[2]);
+    gate[3] = sigmoid2_(pre[3]);
+    c = gate[1] * cprev + gate[0] * gate[2];
+    h = gate[3] * tanh2_(c);
+}
+
 // dh: gradient reaching h_t; dcin: carried dL/dc_t from the later step; cs: c_t;
 // cp: c_{t-1}.  d[] = pre-activation gate gradients (i, f, g, o).
 __device__ __forceinline__ void lstm_cell_bwd(const float g[4], float cs, float cp, float dh,
@@ -936,10 +966,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
         const bool dead = dead_s != 0;
         st = t;
         st_par = step & 1;
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
+        auto cell_one = [&](int e) {
             const int row = e * 8 + wave;
-            sact[e] = t < len[e];
             if (sact[e]) {
                 float pre[4], cn, og[4];
 #pragma unroll
@@ -954,6 +982,36 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_kernel(LstmFwdParams p, 
                 soh[e] = 0.f;
                 shq[e] = (__bf16)0.f;
             }
+        };
+#pragma unroll
+        for (int e = 0; e < NE; ++e) sact[e] = t < len[e];
+#pragma unroll
+        for (int e = 0; e < NE; e += 2) {
+            if (e + 1 < NE && sact[e] && sact[e + 1]) {       // (lengths are wave-uniform)
+                const int row = e * 8 + wave;
+                f32x2 pre[4], cn, hn, og[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    pre[g] = f32x2{g_lds[g][row][col], g_lds[g][row + 8][col]};
+                    if constexpr (!XF) pre[g] = pre[g] + f32x2{pgx[XF ? 0 : e][g], pgx[XF ? 0 : e + 1][g]};
+                }
+                lstm_cell_fwd2(pre, f32x2{c[e], c[e + 1]}, og, cn, hn);
+                const float og0[4] = {og[0].x, og[1].x, og[2].x, og[3].x}, og1[4] = {og[0].y, og[1].y, og[2].y, og[3].y};
+                sog[e] = pack_gates(og0);
+                sog[e + 1] = pack_gates(og1);
+                c[e] = cn.x; c[e + 1] = cn.y;
+                soh[e] = dead ? __builtin_nanf("") : hn.x;
+                soh[e + 1] = dead ? __builtin_nanf("") : hn.y;
+                hq[e] = (__bf16)soh[e]; hq[e + 1] = (__bf16)soh[e + 1];
+                shq[e] = hq[e]; shq[e + 1] = hq[e + 1];
+            } else {
+                cell_one(e);
+                if (e + 1 < NE) cell_one(e + 1);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int row = e * 8 + wave;
             sc[e] = c[e];
             h_lds[(((col >> 4) * 64) + row + 32 * ((col >> 3) & 1)) * 8 + (col & 7)] = hq[e];
         }
