@@ -7,7 +7,8 @@
  *
  * Every function cites the reference lines (relative to /root/reference) whose
  * arithmetic it restates.  Arithmetic is fp32 with the same operation order as
- * the reference's torch ops (logsumexp = max + log(sum(exp(x - max)))).
+ * the reference's torch ops (logsumexp = max + log(sum(exp(x - max)))); the one
+ * fp64 function (oracle_path_logsumexp_f64) is the arbiter for rounding questions.
  *
  * Pinning: tests/test_oracle_golden.py checks these functions against outputs
  * of the imported reference (tests/golden/*.npz, made by
@@ -123,6 +124,100 @@ void oracle_path_logsumexp(const float *lp, int T, int B, int C,
             for (int n = 0; n < N; ++n) tok[n] = (n == 0 ? 0.f : neg_inf) + beta[n];
             logZ_bwd[b] = lse(tok, N);
         }
+    }
+    free(alpha);
+    free(next);
+    free(tok);
+}
+
+/*
+ * fp64 arbiter of oracle_path_logsumexp: the SAME recurrences and operation order
+ * (fst_utils.py:424-471) with every intermediate in double (inputs are the fp32
+ * tensors, widened).  Not a restatement of anything the reference runs — the
+ * reference computes in fp32 — but the yardstick that says, where the fp32 oracle
+ * and the GPU kernel differ, whose rounding it is: tests bound the kernel's error
+ * against this by the fp32 oracle's own error against this.
+ * outputs: logZ [B], grad [T,B,C], logZ_bwd [B], all double.
+ */
+static double lse64(const double *x, int k)
+{
+    double m = x[0];
+    for (int i = 1; i < k; ++i)
+        if (x[i] > m) m = x[i];
+    double s = 0.0;
+    for (int i = 0; i < k; ++i) s += exp(x[i] - m);
+    return m + log(s);
+}
+
+void oracle_path_logsumexp_f64(const float *lp, int T, int B, int C,
+                               const int32_t *lens,
+                               const int32_t *src_in, const int32_t *il_in,
+                               const float *w_in, const float *term,
+                               const int32_t *dst_out, const int32_t *il_out,
+                               const float *w_out,
+                               int N, int Kin, int Kout, int Bg, float neg_inf,
+                               double *logZ, double *grad, double *logZ_bwd)
+{
+    int kmax = Kin > Kout ? Kin : Kout;
+    if (N > kmax) kmax = N;
+    double *alpha = (double *)malloc(sizeof(double) * N);
+    double *next = (double *)malloc(sizeof(double) * N);
+    double *tok = (double *)malloc(sizeof(double) * (size_t)N * kmax);
+    memset(grad, 0, sizeof(double) * (size_t)T * B * C);
+    for (int b = 0; b < B; ++b) {
+        int g = (Bg == 1) ? 0 : b;
+        const int32_t *s_i = src_in + (size_t)g * N * Kin;
+        const int32_t *l_i = il_in + (size_t)g * N * Kin;
+        const float *ww_i = w_in + (size_t)g * N * Kin;
+        const float *tm = term + (size_t)g * N;
+        const int32_t *d_o = dst_out + (size_t)g * N * Kout;
+        const int32_t *l_o = il_out + (size_t)g * N * Kout;
+        const float *ww_o = w_out + (size_t)g * N * Kout;
+        int len = lens[b];
+        double *alphas = (double *)malloc(sizeof(double) * (size_t)(len > 0 ? len : 1) * N);
+
+        for (int n = 0; n < N; ++n) alpha[n] = neg_inf;
+        alpha[0] = 0.0;
+        for (int t = 0; t < len; ++t) {
+            const float *row = lp + ((size_t)t * B + b) * C;
+            memcpy(alphas + (size_t)t * N, alpha, sizeof(double) * N);
+            for (int n = 0; n < N; ++n) {
+                for (int k = 0; k < Kin; ++k)
+                    tok[k] = (double)ww_i[n * Kin + k] + alpha[s_i[n * Kin + k]] +
+                             (double)row[l_i[n * Kin + k]];
+                next[n] = lse64(tok, Kin);
+            }
+            memcpy(alpha, next, sizeof(double) * N);
+        }
+        for (int n = 0; n < N; ++n) tok[n] = alpha[n] + (double)tm[n];
+        double lz = lse64(tok, N);
+        logZ[b] = lz;
+
+        double *beta = alpha;
+        for (int n = 0; n < N; ++n) beta[n] = tm[n];
+        for (int t = len - 1; t >= 0; --t) {
+            const float *row = lp + ((size_t)t * B + b) * C;
+            double *grow = grad + ((size_t)t * B + b) * C;
+            const double *al = alphas + (size_t)t * N;
+            for (int n = 0; n < N; ++n) {
+                double *tk = tok + (size_t)n * Kout;
+                for (int k = 0; k < Kout; ++k)
+                    tk[k] = (double)ww_o[n * Kout + k] + beta[d_o[n * Kout + k]] +
+                            (double)row[l_o[n * Kout + k]];
+                next[n] = lse64(tk, Kout);
+            }
+            for (int n = 0; n < N; ++n) {
+                double a = al[n] - lz;
+                for (int k = 0; k < Kout; ++k)
+                    grow[l_o[n * Kout + k]] += exp(tok[(size_t)n * Kout + k] + a);
+            }
+            memcpy(beta, next, sizeof(double) * N);
+        }
+        if (logZ_bwd) {
+            for (int n = 0; n < N; ++n) tok[n] = (n == 0 ? 0.0 : (double)neg_inf) + beta[n];
+            logZ_bwd[b] = lse64(tok, N);
+        }
+        free(alphas);
     }
     free(alpha);
     free(next);

@@ -63,6 +63,27 @@ def path_logsumexp(lp, lens, graph_matrices, neg_inf=-1e20):
     return dict(logZ=logZ, grad=grad, alphas=alphas, logZ_bwd=logZb)
 
 
+def path_logsumexp_f64(lp, lens, graph_matrices, neg_inf=-1e20):
+    """fp64 arbiter of path_logsumexp: same recurrences and order, double intermediates
+    (oracle_path_logsumexp_f64).  Returns dict(logZ [B], grad [T,B,C], logZ_bwd [B]) float64."""
+    lp = _f32(lp)
+    T, B, C = lp.shape
+    (s_i, l_i, w_i, term, s_o, l_o, w_o, _) = graph_matrices
+    s_i, l_i, s_o, l_o = _i32(s_i), _i32(l_i), _i32(s_o), _i32(l_o)
+    w_i, w_o, term = _f32(w_i), _f32(w_o), _f32(term)
+    Bg, N, Kin = s_i.shape
+    Kout = s_o.shape[2]
+    lens = _i32(lens)
+    logZ = np.zeros(B, np.float64)
+    logZb = np.zeros(B, np.float64)
+    grad = np.zeros((T, B, C), np.float64)
+    lib().oracle_path_logsumexp_f64(
+        _p(lp), T, B, C, _p(lens), _p(s_i), _p(l_i), _p(w_i), _p(term),
+        _p(s_o), _p(l_o), _p(w_o), N, Kin, Kout, Bg,
+        ctypes.c_float(neg_inf), _p(logZ), _p(grad), _p(logZb))
+    return dict(logZ=logZ, grad=grad, logZ_bwd=logZb)
+
+
 def path_forward(lp, lens, graph_matrices, neg_inf=-1e20, viterbi=False):
     """path_reduction's alpha-only scan (fst_utils.py:349-397); with
     viterbi=True also the best-path ilabel per frame

@@ -171,9 +171,15 @@ def ctc_raw_loss_batch(acts, labels, act_lens, label_lens,
                     "dense bicontext CTC with eval_repeats_in_context=False on a label "
                     "sequence with a repeated symbol differs from the FST lattice")
             start = end
-    return ctc_fst_loss(acts, labels, act_lens, label_lens, num_symbols=num_symbols,
-                        context_order=2, normalize_by_dim=normalize_by_dim,
-                        allow_nonblank_selfloops=allow_nonblank_selfloops)
+    # the bicontext matrices emit a CONTEXT-SPECIFIC blank before each symbol
+    # (get_CTC_matrices_bicontext, :123-166): the training lattice with contextual blanks
+    log_probs = get_normalized_acts(acts, act_lens, num_symbols, 2, normalize_by_dim,
+                                    normalize_logits=True)
+    graph_gen = _graph_gen(num_symbols, 2, allow_nonblank_selfloops=allow_nonblank_selfloops,
+                           use_contextual_blanks=True)
+    graph_matrices = graph_gen.get_training_matrices_batch(
+        _labels_to_batch(labels, label_lens), label_lens)
+    return -path_reduction(log_probs, act_lens, graph_matrices)
 
 
 # the reference's per-utterance Python loop (:521-560) computes the same values

@@ -27,6 +27,31 @@ def grad_atol(logZ):
     return max(ATOL_GRAD, 4 * np.finfo(np.float32).eps * float(np.abs(logZ).max()))
 
 
+def assert_posteriors(grad, ref32, lp, lens, mats, oracle_lib):
+    """Posterior (gradient) parity, arbitrated in fp64.
+
+    `ref32` is an fp32 evaluation of the reference arithmetic (the C oracle, or the imported
+    reference's own output from a golden file).  Both it and the kernel round
+    exp(alpha + beta - logZ) in fp32, and on long lattices the two roundings differ by more
+    than a flat 2e-5 (history in DESIGN.md §2: the bound was widened twice after red runs).
+    Instead of a wider bound, the fp64 evaluation of the same recurrences
+    (oracle_path_logsumexp_f64) says whose error it is: the kernel may be off from fp64 by at
+    most max(2e-5, 2 x the fp32 reference's own distance from fp64) in the max norm, and by
+    max(2e-6, 2 x the reference's) in the mean, so a systematic bias cannot hide inside the
+    max-abs bound.  Utterances with no feasible alignment (logZ ~ -1e20: the -1e20 sentinel
+    arithmetic, not a rounding question) are compared with the fp32 reference directly."""
+    f64 = oracle_lib.path_logsumexp_f64(lp, lens, mats)
+    feas = f64['logZ'] > -1e19
+    if (~feas).any():
+        np.testing.assert_allclose(grad[:, ~feas], ref32[:, ~feas], atol=ATOL_GRAD)
+    if not feas.any():
+        return
+    g, r, d = grad[:, feas].astype(np.float64), ref32[:, feas].astype(np.float64), f64['grad'][:, feas]
+    err_k, err_r = np.abs(g - d), np.abs(r - d)
+    assert err_k.max() <= max(ATOL_GRAD, 2 * err_r.max()), (err_k.max(), err_r.max())
+    assert err_k.mean() <= max(ATOL_GRAD / 10, 2 * err_r.mean()), (err_k.mean(), err_r.mean())
+
+
 def dev():
     assert torch.cuda.is_available(), "GPU tests need the MI355X"
     return torch.device('cuda:0')
@@ -59,12 +84,13 @@ def run_fwd(lp, lens, mats, viterbi):
 
 
 @pytest.mark.parametrize('name', LATTICES)
-def test_golden_fwbw(name):
+def test_golden_fwbw(oracle_lib, name):
     g = golden(name + '.npz')
     mats = [g['gm%d' % i] for i in range(8)]
     logZ, grad, zb = run_fwbw(g['lp'], g['lens'], mats, want_bwd=True)
     np.testing.assert_allclose(logZ, g['fwbw_logZ'], rtol=RTOL_LOSS)
     np.testing.assert_allclose(grad, g['fwbw_grad'], atol=grad_atol(logZ))
+    assert_posteriors(grad, g['fwbw_grad'], g['lp'], g['lens'], mats, oracle_lib)
     assert np.abs(zb - logZ).max() < 1e-3                # fst_utils.py:475-479
     for b, l in enumerate(g['lens']):
         assert not grad[l:, b].any()                     # fst_utils.py:448
@@ -124,7 +150,7 @@ def test_seeded_vs_oracle(oracle_lib, name, kw):
     want = oracle_lib.path_logsumexp(lp, lens, mats)
     logZ, grad, zb = run_fwbw(lp, lens, mats, want_bwd=True)
     np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
-    np.testing.assert_allclose(grad, want['grad'], atol=grad_atol(want['logZ']))
+    assert_posteriors(grad, want['grad'], lp, lens, mats, oracle_lib)
     np.testing.assert_allclose(zb, want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
     s, _ = run_fwd(lp, lens, mats, viterbi=False)
     np.testing.assert_allclose(s, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
@@ -171,7 +197,7 @@ def test_generic_graph_with_per_arc_labels(oracle_lib):
     want = oracle_lib.path_logsumexp(lp, lens, mats)
     logZ, grad, zb = run_fwbw(lp, lens, mats, want_bwd=True)
     np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
-    np.testing.assert_allclose(grad, want['grad'], atol=grad_atol(want['logZ']))
+    assert_posteriors(grad, want['grad'], lp, lens, mats, oracle_lib)
     np.testing.assert_allclose(zb, want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
 
 
@@ -208,7 +234,7 @@ def test_grouped_decoding_graph_kernels(oracle_lib, name, order, S, kw, T, B):
                                           want_bwd_total=True)
     torch.cuda.synchronize()
     np.testing.assert_allclose(logZ.cpu().numpy(), want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
-    np.testing.assert_allclose(grad.cpu().numpy(), want['grad'], atol=grad_atol(want['logZ']))
+    assert_posteriors(grad.cpu().numpy(), want['grad'], lp, lens, mats, oracle_lib)
     np.testing.assert_allclose(zb.cpu().numpy(), want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
     s, _ = _native.grouped_forward(torch.from_numpy(lp).to(d), tl, gg, -1e20)
     np.testing.assert_allclose(s.cpu().numpy(), want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
@@ -221,7 +247,7 @@ def test_grouped_decoding_graph_kernels(oracle_lib, name, order, S, kw, T, B):
     lpt = torch.from_numpy(lp).to(d).requires_grad_()
     z = P.path_reduction(lpt, torch.from_numpy(lens), tagged, red_kind='logsumexp')
     z.sum().backward()
-    np.testing.assert_allclose(lpt.grad.cpu().numpy(), want['grad'], atol=grad_atol(want['logZ']))
+    assert_posteriors(lpt.grad.cpu().numpy(), want['grad'], lp, lens, mats, oracle_lib)
 
 
 @pytest.mark.parametrize('order,S,kw', [(1, 49, {}), (2, 7, {}), (2, 49, {}),
@@ -302,7 +328,9 @@ def test_path_reduction_surface():
     w = torch.from_numpy(g['w']).to(d)
     (z * w).sum().backward()
     np.testing.assert_allclose(z.detach().cpu().numpy(), g['fwbw_logZ'], rtol=RTOL_LOSS)
-    np.testing.assert_allclose(lp.grad.cpu().numpy(), g['fwbw_grad_w'], atol=2 * grad_atol(g['fwbw_logZ']))
+    # the gradient is the posterior scaled by the per-utterance weight w_b (|w| up to ~2 here)
+    np.testing.assert_allclose(lp.grad.cpu().numpy(), g['fwbw_grad_w'],
+                               atol=grad_atol(g['fwbw_logZ']) * max(1.0, float(np.abs(g['w']).max())))
     # 4 matrices + autodiff request -> still differentiable
     lp2 = torch.from_numpy(g['lp']).to(d).requires_grad_()
     z2 = P.path_reduction(lp2, lens, mats[:4], red_kind='logsumexp_autodiff')
@@ -360,7 +388,7 @@ def test_log_softmax_and_rowmax(oracle_lib):
 
 SORT_CASES = [
     # few symbols -> long runs of one label: runs > 64 lanes, runs crossing wave boundaries
-    ('s3_long_runs', dict(order=1, S=3, T=150, B=5, Lmax=70, seed=11)),   # runs of ~70 lanes
+    ('s3_long_runs', dict(order=1, S=3, T=230, B=5, Lmax=100, seed=11)),  # runs of ~100 lanes (the round-2 red case)
     ('s5_n301', dict(order=1, S=5, T=200, B=4, Lmax=150, seed=12)),            # H = 320
     ('s49_n255_no_slack', dict(order=1, S=49, T=140, B=6, Lmax=127, seed=13)),  # N = H - 1
     ('s49_n511', dict(order=1, S=49, T=300, B=3, Lmax=255, seed=14)),           # 8 waves per group
@@ -378,10 +406,10 @@ def test_label_sorted_segmented_sums(oracle_lib, name, kw):
     logZ, grad, zb = run_fwbw(lp, lens, mats, want_bwd=True)
     np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
     # long lattices with |logZ| in the hundreds: BOTH fp32 evaluations carry the conditioning
-    # error of exp(alpha + beta - logZ) (the oracle's own rows sum to 1 +- 2e-4 here), so
-    # the bound is twice the one-sided grad_atol
-    tol = 2 * grad_atol(want['logZ'])
-    np.testing.assert_allclose(grad, want['grad'], atol=tol)
+    # error of exp(alpha + beta - logZ) (the oracle's own rows sum to 1 +- 2e-4 here); the
+    # fp64 evaluation arbitrates (assert_posteriors)
+    assert_posteriors(grad, want['grad'], lp, lens, mats, oracle_lib)
+    tol = grad_atol(want['logZ'])
     np.testing.assert_allclose(zb, want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
     # every frame's posteriors sum to one over the classes
     T, B = lp.shape[:2]

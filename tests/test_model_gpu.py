@@ -56,9 +56,9 @@ def cpu_reference_loss(model_cpu, feats, lens, texts, llens, oracle, order=1,
                          if p.grad is not None}
 
 
-def make_batch(B, T, S, L, order, seed):
+def make_batch(B, T, S, L, order, seed, F=40, ch=1):
     g = torch.Generator().manual_seed(seed)
-    feats = torch.randn(B, T, 40, 1, generator=g)
+    feats = torch.randn(B, T, F, ch, generator=g)
     lens = torch.tensor([T - 9 * b for b in range(B)], dtype=torch.int32)
     llens = torch.tensor([max(1, L - 2 * b) for b in range(B)], dtype=torch.int32)
     texts = torch.randint(1, S, (B, L), generator=g, dtype=torch.int32)
@@ -68,17 +68,28 @@ def make_batch(B, T, S, L, order, seed):
     return feats, lens, texts, llens
 
 
-@pytest.mark.parametrize('cfg', ['mono_ctc', 'bigram_ctcg_cde'])
+@pytest.mark.parametrize('cfg', ['mono_ctc', 'bigram_ctcg_cde', 'bigram_ctcg_cde_s49', 'mono_ctc_wsj'])
 def test_speech_model_train_step_matches_cpu(oracle_lib, cfg):
     from att_speech.models import SpeechModel
     torch.manual_seed(7)
+    B, T, L, F, ch = 4, 150, 10, 40, 1
     if cfg == 'mono_ctc':
         S, order, dec_cfg, vocab = 49, 1, DEC_MONO, VOCAB
-    else:   # ctcg_bi_cde.yaml: global normalisation, NGramLinear embedder
+    elif cfg == 'mono_ctc_wsj':
+        # the shipped recipes' feature shape: 80 mel + energy with deltas, feat_dim [-1, 3, 81]
+        # (egs/wsj/yamls/ctc.yaml:8-15) -> conv out 32 x 32 -> LSTM input 1024
+        S, order, dec_cfg, vocab = 49, 1, DEC_MONO, VOCAB
+        F, ch = 81, 3
+    elif cfg == 'bigram_ctcg_cde':   # ctcg_bi_cde.yaml: global normalisation, NGramLinear embedder
         S, order, dec_cfg, vocab = 7, 2, DEC_CDE, VOCAB[:7]
-    B, T, L = 4, 150, 10
-    feats, lens, texts, llens = make_batch(B, T, S, L, order, 11)
-    sb = sample_batch(B=2, T=T)
+    else:
+        # the same recipe at its real size (egs/wsj/yamls/ctcg_bi_cde.yaml:69-74): 49 symbols,
+        # C = 2401 classes, NGramLinear weight net, numerator + the 2401-state x 51-arc
+        # grouped denominator together
+        S, order, dec_cfg, vocab = 49, 2, DEC_CDE, VOCAB
+        B, T, L = 2, 180, 8
+    feats, lens, texts, llens = make_batch(B, T, S, L, order, 11, F, ch)
+    sb = sample_batch(B=2, T=T, F=F, ch=ch)
     model = SpeechModel(ENC, dec_cfg, sb, S ** order, vocab)
     model.train()
     for mod in model.modules():    # BN in eval mode: batch statistics are not
