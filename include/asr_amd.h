@@ -84,6 +84,35 @@ int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
                          void *stream);
 
 /*
+ * The same forward-backward (same arguments, outputs and workspace: replaces
+ * PathLogSumExp.forward, fst_utils.py:403-480) for BAND lattices in the rescaled linear
+ * domain (ABI v13; csrc/lattice_band.inc): state-labelled graphs whose state n is entered
+ * only from {n, n-1, n-2} with arc weights <= 0, N <= 256, C <= 64, Bg == B — the lattices
+ * CTCGraphGen builds for mono-character transcripts (fst_utils.py:603-613; the `2 L + 1`
+ * CTC chain).  One wave per direction keeps four consecutive states per lane (no
+ * transcendental, no LDS and no barrier on the recurrence), alpha / beta are rescaled by
+ * exact powers of two, every posterior row is normalised by its own total.
+ * asr_lattice_fwbw_band_supported says whether the SHAPES qualify; the graph of every
+ * utterance is checked inside the kernel, and an utterance whose graph has another shape,
+ * has no feasible alignment, or whose numbers leave the fp32 range runs the generic
+ * log-domain body in the same launch (correct, slow): route here only graphs known to be
+ * band-shaped (att_speech._native tags the ones its builders make and checks the others on
+ * the host).  ASR_EUNSUPPORTED when the shapes do not qualify.
+ */
+int asr_lattice_fwbw_band_supported(int T, int B, int C, int N, int Kin, int Kout, int Bg);
+int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
+                              const int32_t *lens,
+                              const int32_t *src_in, const int32_t *il_in,
+                              const float *w_in, const float *term,
+                              const int32_t *dst_out, const int32_t *il_out,
+                              const float *w_out,
+                              int N, int Kin, int Kout, int Bg, float neg_inf,
+                              float *out_logZ, float *out_grad,
+                              float *out_logZ_bwd,
+                              void *workspace, int64_t workspace_bytes,
+                              void *stream);
+
+/*
  * Alpha-only scan: path_reduction's autodiff branch evaluated forward
  * (fst_utils.py:349-397) with reduction logsumexp (viterbi == 0) or max
  * (viterbi == 1, fst_utils.py:366-370).

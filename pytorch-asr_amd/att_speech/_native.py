@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -34,6 +34,10 @@ _SIGNATURES = {
     'asr_lattice_fwbw_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp,
                                   _vp, _i64, _vp]),
+    'asr_lattice_fwbw_band_supported': (_i, [_i] * 7),
+    'asr_lattice_fwbw_band_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp,
+                                       _vp, _i64, _vp]),
     'asr_lattice_viterbi_workspace_bytes': (_i64, [_i, _i, _i]),
     'asr_lattice_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _f, _i, _vp, _vp, _vp, _i64,
@@ -142,9 +146,14 @@ class Graph(object):
     """Device-resident int32/f32 copy of the reference's 4 or 8 padded graph
     matrices (fst_utils.py:222-294,491-521)."""
     __slots__ = ('src_in', 'il_in', 'w_in', 'term', 'dst_out', 'il_out',
-                 'w_out', 'Bg', 'N', 'Kin', 'Kout')
+                 'w_out', 'Bg', 'N', 'Kin', 'Kout', 'band')
 
     def __init__(self, graph_matrices, device):
+        # band: every state n is entered only from {n, n-1, n-2} with weights <= 0 (the CTC
+        # chain lattices): lattice_fwbw sends such graphs to asr_lattice_fwbw_band_f32.  Set by
+        # build_ctc_graph, or found here on the host when the matrices arrive as CPU tensors
+        # (the data workers' hand-over, fst_utils.py:491-521); the kernel re-checks per utterance.
+        self.band = False
         if graph_matrices is None:          # filled in by build_ctc_graph
             return
         gm = list(graph_matrices)
@@ -165,9 +174,21 @@ class Graph(object):
         if len(gm) == 8:
             self.dst_out, self.il_out, self.w_out = to_i(gm[4]), to_i(gm[5]), to_f(gm[6])
             self.Kout = self.dst_out.shape[2]
+            self.band = _host_band_check(gm)
         else:
             self.dst_out = self.il_out = self.w_out = None
             self.Kout = 0
+
+
+def _host_band_check(gm):
+    """True when the in-arcs of every state n come from {n, n-1, n-2} with weights <= 0
+    (CPU tensors only: no device read-back to find out)."""
+    src, w = gm[0], gm[2]
+    if src.is_cuda or w.is_cuda or src.dim() != 3 or src.size(1) > 256:
+        return False
+    valid = w > -5e19
+    d = torch.arange(src.size(1)).view(1, -1, 1) - src.long()
+    return bool(((d >= 0) & (d <= 2) & (w <= 0) | ~valid).all())
 
 
 def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
@@ -193,12 +214,17 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(L.asr_lattice_fwbw_f32(
+    # band lattices (CTC chains of mono-character transcripts): the linear-domain kernel
+    # (ASR_LATTICE_BAND=0: the log-domain state-labelled kernel, for A/B runs)
+    use_band = (graph.band and os.environ.get('ASR_LATTICE_BAND', '1') != '0' and
+                L.asr_lattice_fwbw_band_supported(T, B, C, graph.N, graph.Kin, graph.Kout, graph.Bg))
+    entry = L.asr_lattice_fwbw_band_f32 if use_band else L.asr_lattice_fwbw_f32
+    check(entry(
         _p(lp), T, B, C, _p(lens), _p(graph.src_in), _p(graph.il_in),
         _p(graph.w_in), _p(graph.term), _p(graph.dst_out), _p(graph.il_out),
         _p(graph.w_out), graph.N, graph.Kin, graph.Kout, graph.Bg,
         float(neg_inf), _p(logZ), _p(grad), _p(zb), _p(ws), nbytes, _stream()),
-        'asr_lattice_fwbw_f32')
+        'asr_lattice_fwbw_band_f32' if use_band else 'asr_lattice_fwbw_f32')
     if hook is not None:
         ev1.record()
         hook.append((ev0, ev1))
@@ -558,6 +584,7 @@ def build_ctc_graph(labels, label_lens, num_symbols, context_order,
     g.dst_out, g.il_out, g.w_out = ti(), ti(), tf()
     g.term = torch.empty((B, N), dtype=torch.float32, device=dev)
     g.Bg, g.N, g.Kin, g.Kout = B, N, 3, 3
+    g.band = True        # the 2 L + 1 chain in natural state order, both context orders
     check(lib().asr_ctc_graph_build(
         _p(labels), _p(label_lens), B, Lmax, int(num_symbols), int(context_order),
         int(bool(allow_nonblank_selfloops)), int(bool(use_contextual_blanks)),

@@ -35,11 +35,12 @@ struct FwbwParams {
 // in-arcs / out-arcs in registers for the whole scan.  KR == 0: states are
 // strided over the block and arcs are streamed from global memory (L2) every
 // frame (large shared graphs such as the CTC-G denominator).
-// ws_cols: columns of one [frame, utterance] row of the workspace (N for the stand-alone
-// kernel; the row width of the calling kernel's own layout when used as its fallback)
+// b: utterance; alphas_b / astride: this utterance's workspace rows (row t at alphas_b +
+// t * astride, N floats each) — [T,B,N] for the stand-alone kernel, the calling kernel's own
+// region when used as its fallback
 template <int KR>
-__device__ __forceinline__ void lattice_fwbw_generic_body(const FwbwParams &p, float *smem, int ws_cols) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ void lattice_fwbw_generic_body(const FwbwParams &p, float *smem, int b,
+                                                          float *alphas_b, size_t astride) {
     const int tid = threadIdx.x, NT = blockDim.x;
     const int N = p.N, C = p.C, Kin = p.Kin, Kout = p.Kout;
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
@@ -60,8 +61,6 @@ __device__ __forceinline__ void lattice_fwbw_generic_body(const FwbwParams &p, f
     const size_t tstride = (size_t)p.B * C;          // lp / grad frame stride
     const float *lp_b = p.lp + (size_t)b * C;
     float *grad_b = p.grad + (size_t)b * C;
-    const size_t astride = (size_t)p.B * ws_cols;
-    float *alphas_b = p.alphas + (size_t)b * ws_cols;
     const float half_inf = p.neg_inf * 0.5f;
 
     // rows past the utterance end are zeros (fst_utils.py:448)
@@ -236,7 +235,8 @@ __device__ __forceinline__ void lattice_fwbw_generic_body(const FwbwParams &p, f
 template <int KR>
 __global__ void lattice_fwbw_kernel(FwbwParams p) {
     extern __shared__ float smem[];
-    lattice_fwbw_generic_body<KR>(p, smem, p.N);
+    lattice_fwbw_generic_body<KR>(p, smem, blockIdx.x, p.alphas + (size_t)blockIdx.x * p.N,
+                                  (size_t)p.B * p.N);
 }
 
 // ---------------------------------------------------------------------------
@@ -1049,7 +1049,7 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
 #endif
 }
 
-#include "lattice_chain.inc"
+#include "lattice_band.inc"
 
 struct FwdParams {
     const float *lp;
@@ -1222,19 +1222,6 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     const size_t lds_mitm = (size_t)(4 * Npad + 4 * Cpad + 64) * sizeof(float);
     const bool fits32 = (size_t)T * B * C * 4 < (1ull << 31) &&
                         (size_t)(T + 2) * B * round_up(N, 64) * 4 < (1ull << 30);
-    // Opt-in (ASR_LATTICE_CHAIN=1): linear-domain kernel for CTC chain lattices, one wave per
-    // direction + one helper wave each.  Correct (tests/test_lattice_gpu.py) but slower than
-    // the 8-wave kernel below — 199 vs 126 us on the B=512 mono numerator: four states per
-    // lane put ~150 instructions per frame on ONE wave, and a wave issues at most one
-    // instruction per ~4 cycles whatever else the SIMD does (785 / 1380 cycles per frame in
-    // the two halves even at half a workgroup per CU).  DESIGN.md §4.1.
-    const char *chain_env = getenv("ASR_LATTICE_CHAIN");
-    if (chain_env && chain_env[0] == '1' && C <= 64 && N <= chain::NS && Kmax <= 3 && Bg == B &&
-        fits32 && T > 0) {
-        hipLaunchKernelGGL(lattice_fwbw_chain_kernel, dim3(B), dim3(256),
-                           (size_t)chain::LDS_WORDS * sizeof(float), s, p);
-        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
-    }
     if (N <= 512 && Kmax <= 4 && lds_mitm <= 160 * 1024 && fits32) {
         // state-labelled fast path; a workgroup whose graph fails the entry
         // check runs the generic body inside the same launch
@@ -1312,5 +1299,55 @@ extern "C" int asr_lattice_forward_f32(const float *lp, int T, int B, int C,
     }
     const int nt = N >= 1024 ? 1024 : round_up(N, 64);
     hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, s, p);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+// Band lattices (CTC numerators of mono-character transcripts) in the rescaled linear domain:
+// lattice_band.inc.  Same arguments and outputs as asr_lattice_fwbw_f32; the caller asserts
+// nothing — every utterance's graph is checked in the kernel and anything else runs the
+// generic log-domain body in the same launch (correct, slow), so callers route here only
+// graphs they know (or have checked on the host) to be band-shaped.
+extern "C" int asr_lattice_fwbw_band_supported(int T, int B, int C, int N, int Kin, int Kout, int Bg) {
+    const int Kmax = Kin > Kout ? Kin : Kout;
+    return T > 0 && B > 0 && C > 0 && C <= 64 && N > 0 && N <= band::NS && Kmax <= 4 && Bg == B &&
+           (size_t)T * B * C * 4 < (1ull << 31) &&
+           (size_t)(T + 2) * round_up(N, 64) * 4 < (1ull << 31);
+}
+
+extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
+                                         const int32_t *lens,
+                                         const int32_t *src_in, const int32_t *il_in,
+                                         const float *w_in, const float *term,
+                                         const int32_t *dst_out, const int32_t *il_out,
+                                         const float *w_out,
+                                         int N, int Kin, int Kout, int Bg, float neg_inf,
+                                         float *out_logZ, float *out_grad,
+                                         float *out_logZ_bwd,
+                                         void *workspace, int64_t workspace_bytes,
+                                         void *stream) {
+    if (T < 0 || B < 0 || C <= 0 || N <= 0 || Kin <= 0 || Kout <= 0) return ASR_EINVAL;
+    if (Bg != 1 && Bg != B) return ASR_EINVAL;
+    if (B == 0) return ASR_OK;
+    if (!lp || !lens || !src_in || !il_in || !w_in || !term || !dst_out || !il_out ||
+        !w_out || !out_logZ || !out_grad || !workspace)
+        return ASR_EINVAL;
+    if (workspace_bytes < asr_lattice_fwbw_workspace_bytes(T, B, C, N)) return ASR_EINVAL;
+    if (!(neg_inf < 0.f)) return ASR_EINVAL;
+    if (!asr_lattice_fwbw_band_supported(T, B, C, N, Kin, Kout, Bg)) return ASR_EUNSUPPORTED;
+
+    FwbwParams p;
+    p.lp = lp; p.T = T; p.B = B; p.C = C; p.lens = lens;
+    p.src_in = src_in; p.il_in = il_in; p.w_in = w_in; p.term = term;
+    p.dst_out = dst_out; p.il_out = il_out; p.w_out = w_out;
+    p.N = N; p.Kin = Kin; p.Kout = Kout; p.Bg = Bg; p.neg_inf = neg_inf;
+    p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
+    p.alphas = (float *)workspace;
+    // the in-kernel fallback (lattice_fwbw_generic_body<0>) needs 2 Npad + 2 Cpad + 64 words
+    const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
+    size_t lds = (size_t)band::LDS_WORDS * sizeof(float);
+    const size_t lds_gen = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
+    if (lds_gen > lds) lds = lds_gen;
+    const int grid = 8 * ((B + 7) / 8);       // blocks b, b + 8, ... (one XCD) take neighbouring utterances
+    hipLaunchKernelGGL(lattice_fwbw_band_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }

@@ -38,12 +38,14 @@ def assert_posteriors(grad, ref32, lp, lens, mats, oracle_lib):
     (oracle_path_logsumexp_f64) says whose error it is: the kernel may be off from fp64 by at
     most max(2e-5, 2 x the fp32 reference's own distance from fp64) in the max norm, and by
     max(2e-6, 2 x the reference's) in the mean, so a systematic bias cannot hide inside the
-    max-abs bound.  Utterances with no feasible alignment (logZ ~ -1e20: the -1e20 sentinel
-    arithmetic, not a rounding question) are compared with the fp32 reference directly."""
+    max-abs bound.  Utterances with no feasible alignment (logZ ~ -1e20) are left out: their
+    "posteriors" are exp() of differences of +-1e20 sentinels (ulp 9e12), artefacts of the
+    summation order that the reference neither uses nor defines; their logZ is compared by
+    the callers, and until round 3 the bound 4 eps |logZ| silently made this whole comparison
+    vacuous whenever a batch contained one."""
     f64 = oracle_lib.path_logsumexp_f64(lp, lens, mats)
     feas = f64['logZ'] > -1e19
-    if (~feas).any():
-        np.testing.assert_allclose(grad[:, ~feas], ref32[:, ~feas], atol=ATOL_GRAD)
+    assert np.isfinite(grad).all()
     if not feas.any():
         return
     g, r, d = grad[:, feas].astype(np.float64), ref32[:, feas].astype(np.float64), f64['grad'][:, feas]
@@ -61,10 +63,12 @@ def to_t(mats):
     return [torch.from_numpy(np.ascontiguousarray(m)) for m in mats]
 
 
-def run_fwbw(lp, lens, mats, want_bwd=False):
+def run_fwbw(lp, lens, mats, want_bwd=False, band=None):
     from att_speech import _native
     d = dev()
     g = _native.Graph(to_t(mats), d)
+    if band is not None:
+        g.band = band
     logZ, grad, zb = _native.lattice_fwbw(
         torch.from_numpy(lp).to(d), torch.from_numpy(np.asarray(lens, np.int32)).to(d),
         g, -1e20, want_bwd_total=want_bwd)
@@ -419,25 +423,138 @@ def test_label_sorted_segmented_sums(oracle_lib, name, kw):
     np.testing.assert_allclose(grad.sum(-1)[mask], 1.0, atol=max(2e-4, tol))
 
 
-def test_chain_kernel_linear_domain(monkeypatch, oracle_lib):
-    """ASR_LATTICE_CHAIN=1 routes mono-character CTC numerators through the linear-domain
-    chain kernel (csrc/lattice_chain.inc: (mantissa, exponent) pairs, one wave per direction,
-    helper waves, LDS-DMA rings); graphs of another shape, infeasible alignments and very
-    short utterances take its in-kernel generic fallback.  Same goldens, same tolerances."""
-    monkeypatch.setenv('ASR_LATTICE_CHAIN', '1')
-    g = golden('lattice_mono.npz')
-    mats = [g['gm%d' % i] for i in range(8)]
-    logZ, grad, zb = run_fwbw(g['lp'], g['lens'], mats, want_bwd=True)
-    np.testing.assert_allclose(logZ, g['fwbw_logZ'], rtol=RTOL_LOSS)
-    np.testing.assert_allclose(grad, g['fwbw_grad'], atol=grad_atol(logZ))
-    assert np.abs(zb - logZ).max() < 1e-3
-    for name, kw in [CASES[0], CASES[6], SORT_CASES[0], SORT_CASES[2]]:     # incl. ragged / infeasible
+def _band_graph(rng, B, N, C, weighted):
+    """Random band lattices: state n entered from a random subset of {n, n-1, n-2} (always
+    from n-1, so every state is reachable), one label per state, weights 0 or random <= 0,
+    the last two states final."""
+    from att_speech import fst_utils as P
+    per_utt = []
+    for b in range(B):
+        nb = N if b == 0 else int(rng.integers(max(3, N // 2), N + 1))
+        lab = rng.integers(0, C, size=nb)
+        src, dst = [], []
+        for n in range(nb):
+            for d_ in (0, 1, 2):
+                if n - d_ < 0:
+                    continue
+                if d_ == 1 or n == 0 or rng.random() < 0.6:
+                    src.append(n - d_); dst.append(n)
+        src, dst = np.array(src), np.array(dst)
+        w = (-rng.random(len(src)) * 2).astype(np.float32) if weighted else np.zeros(len(src), np.float32)
+        fin = np.full(nb, -1e20, np.float32)
+        fin[-2:] = (-rng.random(2)).astype(np.float32) if weighted else 0.0
+        per_utt.append(P.arcs_to_graph_matrices(nb, src, dst, lab[dst], w, fin))
+    return [m.numpy() for m in P.batch_training_graph_matrices(per_utt)]
+
+
+BAND_CASES = [
+    ('ctc_even_T', dict(order=1, S=49, T=120, B=9, Lmax=40, seed=1), None),
+    ('ctc_odd_T', dict(order=1, S=49, T=121, B=5, Lmax=33, seed=31), None),
+    ('ctc_n255', dict(order=1, S=49, T=300, B=4, Lmax=127, seed=32), None),
+    ('ctc_long_runs', dict(order=1, S=3, T=230, B=5, Lmax=100, seed=11), None),
+    ('ctc_c64', dict(order=1, S=64, T=90, B=7, Lmax=31, seed=15), None),
+    ('ctc_short_and_empty', dict(order=1, S=49, T=30, B=6, Lmax=8, seed=7, lens=[30, 30, 17, 4, 3, 0]), None),
+    ('ctc_t_le_prefetch', dict(order=1, S=49, T=9, B=3, Lmax=3, seed=33), None),
+    ('bigram_classes_s7', dict(order=2, S=7, T=70, B=6, Lmax=20, seed=34), None),
+    ('random_band_unit', None, dict(B=5, N=77, C=23, T=61, weighted=False, seed=35)),
+    ('random_band_weighted', None, dict(B=6, N=130, C=40, T=97, weighted=True, seed=36)),
+    ('random_band_n256', None, dict(B=3, N=256, C=64, T=330, weighted=True, seed=37)),
+]
+
+
+@pytest.mark.parametrize('name,kw,gk', BAND_CASES, ids=[c[0] for c in BAND_CASES])
+def test_band_kernel_linear_domain(oracle_lib, name, kw, gk):
+    """asr_lattice_fwbw_band_f32 (csrc/lattice_band.inc): alpha / beta as rescaled fp32 numbers,
+    one wave per direction, posterior rows normalised by their own totals.  Against the fp32
+    oracle for logZ, the fp64 arbiter for the posteriors; rows that sum to one to a few ulp
+    prove the linear-domain path (not its in-kernel log-domain fallback) produced them."""
+    if kw is not None:
         lp, lens, mats = _random_case(**kw)
-        want = oracle_lib.path_logsumexp(lp, lens, mats)
-        logZ, grad, zb = run_fwbw(lp, lens, mats, want_bwd=True)
-        np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
-        np.testing.assert_allclose(grad, want['grad'], atol=2 * grad_atol(want['logZ']))
-        np.testing.assert_allclose(zb, want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
+    else:
+        rng = np.random.default_rng(gk['seed'])
+        mats = _band_graph(rng, gk['B'], gk['N'], gk['C'], gk['weighted'])
+        T, B = gk['T'], gk['B']
+        lens = np.sort(rng.integers(T // 2, T + 1, size=B))[::-1].astype(np.int32).copy()
+        lens[0] = T
+        lp = torch.log_softmax(torch.from_numpy(
+            rng.standard_normal((T, B, gk['C'])).astype(np.float32) * 2), -1).numpy()
+    from att_speech import _native
+    assert _native._host_band_check(to_t(mats))
+    want = oracle_lib.path_logsumexp(lp, lens, mats)
+    logZ, grad, zb = run_fwbw(lp, lens, mats, want_bwd=True, band=True)
+    np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
+    np.testing.assert_allclose(zb, want['logZ_bwd'], rtol=RTOL_LOSS, atol=1e-4)
+    assert_posteriors(grad, want['grad'], lp, lens, mats, oracle_lib)
+    T, B = lp.shape[:2]
+    lens = np.asarray(lens)
+    for b in range(B):
+        assert not grad[lens[b]:, b].any()
+    # utterances the linear-domain path keeps: feasible, >= 4 frames, and with room to spare —
+    # when the frames barely suffice for the states, nearly all of alpha's mass sits on states
+    # that can no longer reach the end, the live part underflows relative to the frame maximum,
+    # the kernel notices that its three values of Z disagree and redoes the utterance in the
+    # log domain (seen: 183 states in 130 frames, 255 states in 127; asserted here only for
+    # utterances with at least one frame per state)
+    nstates = np.array([(np.asarray(mats[2][b if mats[2].shape[0] > 1 else 0]) > -1e19).any(-1).sum()
+                        for b in range(B)])
+    lin = (want['logZ'] > -1e19) & (lens >= 4) & (lens >= nstates)
+    assert lin.sum() >= 1
+    mask = (np.arange(T)[:, None] < lens[None, :]) & lin[None, :]
+    np.testing.assert_allclose(grad.astype(np.float64).sum(-1)[mask], 1.0, atol=3e-6)
+    # and the log-domain kernel (its own parity: the tests above) agrees with it: two fp32
+    # evaluations, each within ~2x the fp32 oracle's own distance from fp64
+    logZ2, grad2, _ = run_fwbw(lp, lens, mats, want_bwd=True, band=False)
+    np.testing.assert_allclose(logZ, logZ2, rtol=RTOL_LOSS, atol=1e-5)
+    f64 = oracle_lib.path_logsumexp_f64(lp, lens, mats)
+    feas = f64['logZ'] > -1e19
+    err32 = np.abs(want['grad'][:, feas] - f64['grad'][:, feas]).max()
+    assert np.abs(grad2[:, feas] - grad[:, feas]).max() <= max(ATOL_GRAD, 4 * err32)
+
+
+def test_band_kernel_falls_back_inside_the_launch(oracle_lib):
+    """What the linear domain cannot hold is detected and redone by the log-domain body of
+    the same launch: (a) emissions far above 0 (raw logits: overflow), (b) a transcript the
+    model rules out with probabilities of e^-200 per frame (total underflow: Z == 0 at the
+    meeting point), (c) a graph that is not a band (caller's tag wrong)."""
+    kw = dict(order=1, S=49, T=64, B=4, Lmax=12, seed=41)
+    lp, lens, mats = _random_case(**kw)
+    # (a)
+    big = (lp * -8.0 + 60.0).astype(np.float32)
+    want = oracle_lib.path_logsumexp(big, lens, mats)
+    logZ, grad, zb = run_fwbw(big, lens, mats, want_bwd=True, band=True)
+    np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS)
+    assert_posteriors(grad, want['grad'], big, lens, mats, oracle_lib)
+    # (b) every class but the blank at -200: all label emissions underflow in the linear domain
+    peaky = np.full_like(lp, -200.0)
+    peaky[..., 0] = 0.0
+    want = oracle_lib.path_logsumexp(peaky, lens, mats)
+    assert (want['logZ'] < -1000).sum() >= 2 and (want['logZ'] > -1e19).all()
+    logZ, grad, zb = run_fwbw(peaky, lens, mats, want_bwd=True, band=True)
+    np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS)
+    assert_posteriors(grad, want['grad'], peaky, lens, mats, oracle_lib)
+    # (c) per-arc labels: not state-labelled
+    from att_speech import fst_utils as P
+    rng = np.random.default_rng(42)
+    C, T, B, N = 11, 40, 3, 30
+    per_utt = []
+    for b in range(B):
+        src, dst = [], []
+        for n in range(N):
+            for d_ in (0, 1, 2):
+                if n - d_ >= 0:
+                    src.append(n - d_); dst.append(n)
+        src, dst = np.array(src), np.array(dst)
+        fin = np.full(N, -1e20, np.float32)
+        fin[-1] = 0.0
+        per_utt.append(P.arcs_to_graph_matrices(
+            N, src, dst, rng.integers(0, C, len(src)), np.zeros(len(src), np.float32), fin))
+    mats = [m.numpy() for m in P.batch_training_graph_matrices(per_utt)]
+    lp = torch.log_softmax(torch.from_numpy(rng.standard_normal((T, B, C)).astype(np.float32)), -1).numpy()
+    lens = np.array([40, 36, 30], np.int32)
+    want = oracle_lib.path_logsumexp(lp, lens, mats)
+    logZ, grad, zb = run_fwbw(lp, lens, mats, want_bwd=True, band=True)
+    np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS)
+    assert_posteriors(grad, want['grad'], lp, lens, mats, oracle_lib)
 
 
 def test_full_size_bichar_numerator_properties():

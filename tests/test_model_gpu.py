@@ -128,8 +128,11 @@ def test_speech_model_train_step_matches_cpu(oracle_lib, cfg):
         g, w = p.grad.cpu(), want_g2['decoder.' + k]
         scale = max(float(w.abs().max()), 1e-3)
         # relative to the tensor's largest gradient, plus an absolute floor for
-        # gradients that cancel analytically (e.g. a global bias under CTC-G)
-        assert float((g - w).abs().max()) <= 2e-3 * scale + 1e-5, k
+        # gradients that cancel analytically (e.g. a global bias under CTC-G: numerator and
+        # denominator posteriors both sum to the frame count); the floor is the fp32
+        # summation noise of that cancellation, which grows with the number of classes
+        floor = 1e-5 * max(1.0, (S ** order) / 49.0) ** 0.5
+        assert float((g - w).abs().max()) <= 2e-3 * scale + floor, (k, float((g - w).abs().max()))
     ge = enc_c.grad
     assert float((enc_in.grad.cpu() - ge).abs().max()) <= 2e-3 * float(ge.abs().max()) + 1e-6
     # graph matrices handed over by the data pipeline (first-batch self check,

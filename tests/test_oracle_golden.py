@@ -29,6 +29,24 @@ def test_fwbw_matches_reference(oracle_lib, name):
 
 
 @pytest.mark.parametrize('name', LATTICES)
+def test_fp64_arbiter_agrees_with_reference(oracle_lib, name):
+    """oracle_path_logsumexp_f64 (the yardstick of tests/test_lattice_gpu.py::
+    assert_posteriors) is the same recurrence: on these short lattices it agrees with the
+    imported reference's fp32 outputs to fp32 rounding, and its posterior rows sum to one."""
+    g = golden(name + '.npz')
+    mats = [g['gm%d' % i] for i in range(8)]
+    r = oracle_lib.path_logsumexp_f64(g['lp'], g['lens'], mats)
+    assert r['grad'].dtype == np.float64
+    np.testing.assert_allclose(r['logZ'], g['fwbw_logZ'], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(r['grad'], g['fwbw_grad'], rtol=0, atol=1e-4)   # the fp32 side's rounding (3e-5 at |logZ| ~ 100)
+    np.testing.assert_allclose(r['logZ_bwd'], r['logZ'], rtol=1e-12, atol=1e-9)
+    for b, l in enumerate(g['lens']):
+        assert not r['grad'][l:, b].any()
+        if r['logZ'][b] > -1e19 and name.startswith('lattice_mono'):
+            np.testing.assert_allclose(r['grad'][:l, b].sum(-1), 1.0, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', LATTICES)
 def test_forward_and_viterbi_match_reference(oracle_lib, name):
     g = golden(name + '.npz')
     mats = [g['gm%d' % i] for i in range(8)]
