@@ -456,8 +456,8 @@ BAND_CASES = [
     ('ctc_short_and_empty', dict(order=1, S=49, T=30, B=6, Lmax=8, seed=7, lens=[30, 30, 17, 4, 3, 0]), None),
     ('ctc_t_le_prefetch', dict(order=1, S=49, T=9, B=3, Lmax=3, seed=33), None),
     ('bigram_classes_s7', dict(order=2, S=7, T=70, B=6, Lmax=20, seed=34), None),
-    ('random_band_unit', None, dict(B=5, N=77, C=23, T=61, weighted=False, seed=35)),
-    ('random_band_weighted', None, dict(B=6, N=130, C=40, T=97, weighted=True, seed=36)),
+    ('random_band_unit', None, dict(B=5, N=77, C=23, T=91, weighted=False, seed=35)),
+    ('random_band_weighted', None, dict(B=6, N=130, C=40, T=161, weighted=True, seed=36)),
     ('random_band_n256', None, dict(B=3, N=256, C=64, T=330, weighted=True, seed=37)),
 ]
 
