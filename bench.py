@@ -15,8 +15,13 @@ relays rank 0's JSON line and exits with the child's code.
 Prints ONE JSON line on rank 0 (see the contract in the task statement), with
   roofline        — the lattice forward-backward scan kernel of the step, HBM-bound,
                     timed live with events on the stream it is launched on;
-  roofline_bichar — the same kernel on the bi-char numerator (C = 2401, B = 512),
-                    launched alone after the timed region (N = 1 only);
+  roofline_bichar — the scan on the bi-char numerator (C = 2401, B = 512), launched alone
+                    after the timed region (N = 1 only); `frac` on algorithmic bytes,
+                    `frac_traffic` on the HBM bytes the counters saw;
+  extra_workloads — the training step of BASELINE configs 3 and 5 beside the headline:
+                    bi-char CTC (ctc_bi) and bi-char CTC-G + CDE (ctcg_bi_cde), a few timed
+                    steps each after the headline region (with N > 1: the bi-char step, the
+                    model of config 5, on all ranks);
   roofline_mfma   — dense flops of the step / step time / 2.5 PFLOP/s (bf16 dense peak);
   decode          — BASELINE config 4 beside the headline: utterances/s of the TCN attention
                     decoder with beam 10 (N = 1 only);
@@ -37,8 +42,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-# pinned MIOpen solver choice for the conv layers that still go through torch
-# (see pytorch-asr_amd/miopen_db/README.md); must be set before MIOpen loads
+# pinned MIOpen solver choice for convolution shapes outside csrc/conv.hip (none in the
+# bench workloads; see pytorch-asr_amd/miopen_db/README.md); must be set before MIOpen loads
 os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(ROOT, 'pytorch-asr_amd', 'miopen_db'))
 
 
@@ -261,7 +266,9 @@ def bichar_numerator_roofline(dev, B=512, Tp=334, iters=10, traffic=None):
     return {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan), bi-char numerator '
                                       'C=2401 B=%d T\'=%d' % (B, Tp),
             'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
-            'traffic': traffic, 'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': ms}
+            'traffic': traffic,
+            'frac_traffic': (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': ms}
 
 
 def tcn_decode_rate(dev, B=64, T=1000, beam=10, steps=120):
@@ -292,6 +299,68 @@ def tcn_decode_rate(dev, B=64, T=1000, beam=10, steps=120):
             'value': B / dt, 'unit': 'utt/s', 'ms_per_batch': dt * 1e3, 'batch': B, 'beam': beam,
             'label_steps': steps, 'frames': T,
             'workload': 'lattice_decoding/tcn.yaml dimensions, random weights, fixed label-step budget'}
+
+
+def time_extra_workload(workload, B, T, steps, warmup, dev, rank, world, hooks_on=True):
+    """A few timed training steps of another BASELINE config (same step definition, same
+    hooks, same barrier / max-over-ranks timing as the headline) -> dict for `extra_workloads`."""
+    from att_speech.dp import FlatGradBucket, broadcast_parameters, train_step
+    from att_speech.modules.hooks import GradientClipping, PolyakDecay
+    from att_speech.models import SpeechModel
+    order = WORKLOADS[workload][0]
+    C = S ** order
+    feats, lens, texts, llens = synthetic_batch(B, T, rank, order)
+    enc_cfg, dec_cfg = model_config(order, workload)
+    torch.manual_seed(1234)
+    sb = {'features': feats[:2].clone(), 'features_lengths': lens[:2].clone(), 'spkids': None}
+    model = SpeechModel(enc_cfg, dec_cfg, sb, C, [str(i) for i in range(S)]).to(dev)
+    broadcast_parameters(model)
+    bucket = FlatGradBucket(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    feats_d = feats.to(dev)
+    hooks = []
+    if hooks_on:
+        scale = B * world / 16.0
+        hooks = [GradientClipping(clip_norm=10000.0 * scale, skip_step_norm=100000.0 * scale),
+                 PolyakDecay(decay_rates=[0.9998])]
+        for h in hooks:
+            h.pre_run(model, opt)
+    skipped = []
+
+    def step(record):
+        with contextlib.redirect_stdout(sys.stderr):
+            out, skip = train_step(model, opt, ((feats_d, lens, None, texts, llens), {}),
+                                   hooks=hooks, bucket=bucket)
+        if record:
+            skipped.append(bool(skip))
+        return out['loss']
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(warmup):
+        step(False)
+    fence()
+    t0 = time.time()
+    for _ in range(steps):
+        loss = step(True)
+    fence()
+    t = torch.tensor([time.time() - t0], dtype=torch.float64, device=dev)
+    frames = torch.tensor([float(lens.sum())], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(frames, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    res = {'workload': '%s (egs/wsj/yamls/%s.yaml shapes), fwd+bwd+hooks+Adam, synthetic 40-dim x %d-frame fbank'
+                       % (workload, WORKLOADS[workload][1], T),
+           'batch_per_gpu': B, 'classes': C, 'steps': steps, 'warmup': warmup,
+           'ms_per_step': dt / steps * 1e3, 'frames_per_s': float(frames.item()) * steps / dt,
+           'optimizer_steps': len(skipped) - sum(skipped), 'final_loss': float(loss.detach())}
+    del model, bucket, opt, feats_d
+    torch.cuda.empty_cache()
+    return res
 
 
 def self_launch(a, argv):
@@ -346,7 +415,7 @@ def dry_run(a, world, rank):
 
 def pmc_traffic(order, B, T, kernel_tag=None):
     """HBM bytes per lattice launch from the PMC passes committed under profiles/
-    (r02_pmc_step_fetch_write.json: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    (r03_pmc_step_fetch_write.json: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
     runs of bench.py summarised by tools/pmc_summary.py; FETCH_SIZE counts half of a
     4 B/lane coalesced stream on gfx950 - calibrated on log_softmax_fwd - so
     traffic = 2*FETCH + WRITE).  bench.py cannot collect counters itself; the figure
@@ -354,9 +423,9 @@ def pmc_traffic(order, B, T, kernel_tag=None):
     the bi-char numerator launch of `roofline_bichar` is part of the same runs)."""
     if T != 1000:
         return None
-    k = kernel_tag or ('lattice_fwbw_sl_kernel<3, 8, 1>' if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>')
+    k = kernel_tag or ('lattice_fwbw_band_kernel' if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>')
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_step_fetch_write.json')))
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_step_fetch_write.json')))
         if pmc.get('batch') != B:
             return None
         e = next(v for n, v in pmc['kernels'].items() if k in n)
@@ -509,6 +578,18 @@ def main():
     if lstm_err is not None:
         lstm_err()                               # raises if a persistent-LSTM hand-off timed out
 
+    # BASELINE configs 3 and 5 beside the headline (every rank takes part when N > 1)
+    extra = []
+    if not a.no_extra and a.workload in (None, 'ctc') and order == 1:
+        final_state = model.state_dict() if rank == 0 else None
+        del feats_d, bucket, opt
+        torch.cuda.empty_cache()
+        for wl, wb in ([('ctc_bi', 512), ('ctcg_bi_cde', 256)] if world == 1 else [('ctc_bi', 512)]):
+            progress('extra workload %s' % wl)
+            extra.append(time_extra_workload(wl, wb, T, 5, 2, dev, rank, world, not a.no_hooks))
+    else:
+        final_state = model.state_dict() if rank == 0 else None
+
     if rank == 0:
         lat_ms = [s.elapsed_time(e) for (s, e) in lat_events]
         lat_ms = float(np.mean(lat_ms)) if lat_ms else float('nan')
@@ -536,7 +617,7 @@ def main():
                        'classes': C, 'parallelism': 'dp%d' % world,
                        'optimizer_steps': len(skipped) - sum(skipped),
                        'first_loss': loss0, 'final_loss': float(loss.detach())},
-            'roofline': {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan)',
+            'roofline': {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan: lattice_fwbw_band_kernel for the mono-char chains)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': pmc_traffic(order, B, T),
                          'algorithmic_bytes_per_launch': alg,
@@ -547,17 +628,16 @@ def main():
                               'flops_per_step_per_gpu': flops},
         }
         if world == 1 and not a.no_extra:
-            del feats_d
-            torch.cuda.empty_cache()
             progress('bi-char numerator roofline launch')
             res['roofline_bichar'] = bichar_numerator_roofline(
                 dev, traffic=pmc_traffic(2, B, T, 'lattice_fwbw_sl_kernel<3, 8, 0>'))
             torch.cuda.empty_cache()
             progress('stage-2 decode rate')
             res['decode'] = tcn_decode_rate(dev)
+        res['extra_workloads'] = extra
         if world == 1 and not a.no_cpu_baseline and a.workload != 'ctcg_bi_cde':
             progress('loss delta + timing the CPU baseline (about 25 s)')
-            res['cpu_baseline'], res['loss_delta'] = cpu_baseline(T, order, dev, model.state_dict())
+            res['cpu_baseline'], res['loss_delta'] = cpu_baseline(T, order, dev, final_state)
         else:
             res['cpu_baseline'] = None
             res['loss_delta'] = None

@@ -191,6 +191,43 @@ def _host_band_check(gm):
     return bool(((d >= 0) & (d <= 2) & (w <= 0) | ~valid).all())
 
 
+# Policy state of the band kernel (csrc/lattice_band.inc): it redoes, inside the launch and ~10x
+# slower, the utterances whose numbers leave what a wave-wide scale factor can hold — typically
+# ALL utterances of a batch while a CTC model is in its blank-collapse phase (blank ~1, labels
+# ~1e-3: alpha peaks at the first states, beta at the last, the paths that matter sit 2^-300
+# below both).  The kernel counts them; the count of one call is read (without a sync: pinned
+# copy + event) before a later call, and when more than a tenth of a batch was redone the next
+# `_BAND_COOLDOWN` calls go to the log-domain kernel, which does not care.
+_BAND_STATE = {'cool': 0, 'pending': None}
+_BAND_COOLDOWN = 64
+
+
+def _band_policy_allows():
+    st = _BAND_STATE
+    pend = st['pending']
+    if pend is not None and pend[1].query():
+        redone, batch = int(pend[0].item()), pend[2]
+        st['pending'] = None
+        if redone * 10 > batch:
+            st['cool'] = _BAND_COOLDOWN
+    if st['cool'] > 0:
+        st['cool'] -= 1
+        return False
+    return True
+
+
+def _band_policy_record(ws, B, T, N):
+    if _BAND_STATE['pending'] is not None:
+        return
+    wc = (N + 63) // 64 * 64
+    off = B * (T + 2) * wc * 4
+    host = torch.empty(1, dtype=torch.int32).pin_memory()
+    host.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _BAND_STATE['pending'] = (host, ev, B)
+
+
 def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
     """asr_lattice_fwbw_f32: returns (logZ [B], grad [T,B,C], logZ_bwd|None)."""
     lp = _dev(lp, torch.float32, 'log_probs')
@@ -216,8 +253,11 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
         ev0.record()
     # band lattices (CTC chains of mono-character transcripts): the linear-domain kernel
     # (ASR_LATTICE_BAND=0: the log-domain state-labelled kernel, for A/B runs)
-    use_band = (graph.band and os.environ.get('ASR_LATTICE_BAND', '1') != '0' and
+    band_env = os.environ.get('ASR_LATTICE_BAND', '1')        # 0: never, 2: always (no policy)
+    use_band = (graph.band and band_env != '0' and
                 L.asr_lattice_fwbw_band_supported(T, B, C, graph.N, graph.Kin, graph.Kout, graph.Bg))
+    if use_band and band_env != '2' and not _band_policy_allows():
+        use_band = False
     entry = L.asr_lattice_fwbw_band_f32 if use_band else L.asr_lattice_fwbw_f32
     check(entry(
         _p(lp), T, B, C, _p(lens), _p(graph.src_in), _p(graph.il_in),
@@ -228,6 +268,16 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
     if hook is not None:
         ev1.record()
         hook.append((ev0, ev1))
+    if use_band and band_env != '2':
+        _band_policy_record(ws, B, T, graph.N)
+    if use_band and os.environ.get('ASR_LATTICE_BAND_DEBUG'):
+        # development aid: why utterances were redone by the in-kernel log-domain body (the last
+        # word of each utterance's workspace region, csrc/lattice_band.inc); synchronises
+        wc = (graph.N + 63) // 64 * 64
+        why = ws[:B * (T + 2) * wc * 4].view(torch.int32).view(B, (T + 2) * wc)[:, -1].cpu()
+        vals, cnts = torch.unique(why, return_counts=True)
+        print('[band] B=%d T=%d N=%d fallback reasons {code: utterances} %s' % (
+            B, T, graph.N, dict(zip(vals.tolist(), cnts.tolist()))), flush=True)
     return logZ, grad, zb
 
 

@@ -1348,6 +1348,10 @@ extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
     const size_t lds_gen = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
     if (lds_gen > lds) lds = lds_gen;
     const int grid = 8 * ((B + 7) / 8);       // blocks b, b + 8, ... (one XCD) take neighbouring utterances
+    // the count of utterances redone by the fallback body: first word of the workspace's tail pad
+    if (hipMemsetAsync((float *)workspace + (size_t)B * (size_t)(T + 2) * round_up(N, 64), 0, 4,
+                       (hipStream_t)stream) != hipSuccess)
+        return ASR_ELAUNCH;
     hipLaunchKernelGGL(lattice_fwbw_band_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates the measurements behind profiles/r02_* on the GPU box (run through gpurun from
+# Regenerates the measurements behind profiles/r03_* on the GPU box (run through gpurun from
 # the repo root: `gpurun --timeout 1200 -- bash tools/refresh_profiles.sh`); copy the results
 # from gpurun_out/refresh/ into profiles/ afterwards (tools/kstats.py, tools/pmc_summary.py,
 # tools/mfma_busy.py summarise them).
@@ -9,7 +9,7 @@ O=$R/gpurun_out/refresh
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-extra --no-cpu-baseline --steps 10 --warmup 3 > $O/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > $O/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mfma -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/mfma.log 2>&1
