@@ -219,7 +219,7 @@ def _band_policy_allows():
 def _band_policy_record(ws, B, T, N):
     if _BAND_STATE['pending'] is not None:
         return
-    wc = (N + 63) // 64 * 64
+    wc = (N + 63) // 64 * 64 + 64
     off = B * (T + 2) * wc * 4
     host = torch.empty(1, dtype=torch.int32).pin_memory()
     host.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
@@ -273,7 +273,7 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
     if use_band and os.environ.get('ASR_LATTICE_BAND_DEBUG'):
         # development aid: why utterances were redone by the in-kernel log-domain body (the last
         # word of each utterance's workspace region, csrc/lattice_band.inc); synchronises
-        wc = (graph.N + 63) // 64 * 64
+        wc = (graph.N + 63) // 64 * 64 + 64
         why = ws[:B * (T + 2) * wc * 4].view(torch.int32).view(B, (T + 2) * wc)[:, -1].cpu()
         vals, cnts = torch.unique(why, return_counts=True)
         print('[band] B=%d T=%d N=%d fallback reasons {code: utterances} %s' % (

@@ -1177,9 +1177,10 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 extern "C" int64_t asr_lattice_fwbw_workspace_bytes(int T, int B, int C, int N) {
     (void)C;
     if (T < 0 || B < 0 || N < 0) return -1;
-    // [T+2, B, round_up(N,64)] f32 (+1 slot: beta_len, +1: spare)
+    // [T+2, B, round_up(N,64)] f32 (+1 slot: beta_len, +1: spare); the band kernel keeps one
+    // exponent word per lane and row beside its value rows: + [T+2, B, 64]
     const int64_t H = (N + 63) / 64 * 64;
-    return (int64_t)(T + 2) * B * H * (int64_t)sizeof(float) + 256;
+    return (int64_t)(T + 2) * B * (H + 64) * (int64_t)sizeof(float) + 256;
 }
 
 extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
@@ -1311,7 +1312,7 @@ extern "C" int asr_lattice_fwbw_band_supported(int T, int B, int C, int N, int K
     const int Kmax = Kin > Kout ? Kin : Kout;
     return T > 0 && B > 0 && C > 0 && C <= 64 && N > 0 && N <= band::NS && Kmax <= 4 && Bg == B &&
            (size_t)T * B * C * 4 < (1ull << 31) &&
-           (size_t)(T + 2) * round_up(N, 64) * 4 < (1ull << 31);
+           (size_t)(T + 2) * (round_up(N, 64) + 64) * 4 < (1ull << 31);
 }
 
 extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
@@ -1349,7 +1350,7 @@ extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
     if (lds_gen > lds) lds = lds_gen;
     const int grid = 8 * ((B + 7) / 8);       // blocks b, b + 8, ... (one XCD) take neighbouring utterances
     // the count of utterances redone by the fallback body: first word of the workspace's tail pad
-    if (hipMemsetAsync((float *)workspace + (size_t)B * (size_t)(T + 2) * round_up(N, 64), 0, 4,
+    if (hipMemsetAsync((float *)workspace + (size_t)B * (size_t)(T + 2) * (round_up(N, 64) + 64), 0, 4,
                        (hipStream_t)stream) != hipSuccess)
         return ASR_ELAUNCH;
     hipLaunchKernelGGL(lattice_fwbw_band_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);

@@ -11,6 +11,7 @@ print('lens', lens, 'N', mats[0].shape)
 want = oracle.path_logsumexp_f64(lp, lens, mats)
 logZ, grad, zb = T.run_fwbw(lp, lens, mats, want_bwd=True, band=True)
 print('logZ', logZ, want['logZ'])
+print('zb  ', zb, want['logZ_bwd'])
 nanpos = np.argwhere(~np.isfinite(grad))
 print('non-finite entries', len(nanpos), nanpos[:12].tolist())
 if len(nanpos):

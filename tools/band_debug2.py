@@ -48,19 +48,38 @@ for t in range(Ln - 1, -1, -1):
     x = be[t + 1] * e[t, lab]
     s = W[0] * x; s[:-1] += W[1, 1:] * x[1:]; s[:-2] += W[2, 2:] * x[2:]
     be[t] = s / s.max()
-wcols = (g.N + 63) // 64 * 64
+wc0 = (g.N + 63) // 64 * 64
+wreg = (Tn + 2) * (wc0 + 64)
 N4 = (N + 3) // 4 * 4
-reg = ws[b * (Tn + 2) * wcols:(b + 1) * (Tn + 2) * wcols]
+reg = ws[b * wreg:(b + 1) * wreg]
+kreg = reg[(Tn + 2) * wc0:].view(np.int32)
+nbad = 0
 for slot in range(Ln):
     row = reg[slot * N4: slot * N4 + N].astype(np.float64)
+    kk = kreg[slot * 64: slot * 64 + (N + 3) // 4].astype(np.float64)
     exp = al[slot + 1] if slot < m else be[slot + 1]
-    ok = exp > 1e-30
-    ratio = row[ok] / exp[ok]
-    ratio = ratio / np.median(ratio)
-    badn = np.nonzero(ok)[0][np.abs(ratio - 1) > 1e-3]
-    if len(badn):
-        print('slot %d (%s): bad states %s ratios %s' % (slot, 'alpha' if slot < m else 'beta', badn.tolist()[:12],
-              np.round(ratio[np.abs(ratio - 1) > 1e-3][:12], 4).tolist()))
+    ok = (exp > 1e-200) & (row > 0)
+    l2 = np.log2(row[ok]) - np.repeat(kk, 4)[:N][ok] - np.log2(exp[ok])
+    dev = l2 - np.median(l2)
+    badn = np.nonzero(ok)[0][np.abs(dev) > 1e-2]
+    miss = np.nonzero((exp > 1e-30 * exp.max()) & (row <= 0))[0]
+    if (len(badn) or len(miss)) and nbad < 25:
+        nbad += 1
+        print('slot %d (%s): off states %s dev %s | zero-but-expected %s | K lanes %s' % (
+            slot, 'alpha' if slot < m else 'beta', badn.tolist()[:8], np.round(dev[np.abs(dev) > 1e-2][:8], 2).tolist(),
+            miss.tolist()[:8], kk[:6].astype(int).tolist()))
 print('done', logZ.cpu().numpy())
 for bb in range(B):
-    print('utt', bb, 'fallback reason', int(ws[(bb + 1) * (Tn + 2) * wcols - 1].view(np.int32)))
+    print('utt', bb, 'fallback reason', int(ws[(bb + 1) * wreg - 1].view(np.int32)))
+for slot in [int(x) for x in os.environ.get('DBG_SLOTS', '').split(',') if x]:
+    row = reg[slot * N4: slot * N4 + 12].astype(np.float64)
+    kk = kreg[slot * 64: slot * 64 + 3]
+    exp = (al[slot + 1] if slot < m else be[slot + 1])[:12]
+    print('slot', slot, 'K', kk.tolist())
+    print('   log2 v   ', np.round(np.log2(np.maximum(row, 1e-300)), 2).tolist())
+    print('   log2 true', np.round(np.log2(np.maximum(row, 1e-300)) - np.repeat(kk, 4), 2).tolist())
+    print('   log2 want', np.round(np.log2(np.maximum(exp, 1e-300)), 2).tolist())
+for d_ in (0, 1):
+    rec = reg[Tn * wc0 + 64 + d_ * 16: Tn * wc0 + 64 + d_ * 16 + 16]
+    print('dir', d_, 'par,lane,kx,ky,F0', rec[:5].tolist(), 'log2 x', np.round(np.log2(np.maximum(rec[5:9], 1e-300)), 1).tolist(),
+          'log2 y', np.round(np.log2(np.maximum(rec[9:13], 1e-300)), 1).tolist(), 'q', rec[13:16].tolist())

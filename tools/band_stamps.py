@@ -24,21 +24,19 @@ for _ in range(3):
         p(g.dst_out), p(g.il_out), p(g.w_out), g.N, g.Kin, g.Kout, g.Bg, -1e20, p(logZ), p(grad), None, p(ws), nbytes,
         _native._stream()), 'band')
 torch.cuda.synchronize()
-wcols = (g.N + 63) // 64 * 64
-w = ws.cpu().numpy()[:B * (T + 2) * wcols].reshape(B, T + 2, wcols)
-raw = w[:, T, :32].reshape(B, 4, 8)
+wc0 = (g.N + 63) // 64 * 64
+wreg = (T + 2) * (wc0 + 64)
+w = ws.cpu().numpy()[:B * wreg].reshape(B, wreg)
+raw = w[:, T * wc0:T * wc0 + 32].reshape(B, 4, 8)
 st = raw[:, :, :5]
 hw = raw[:, :, 5].copy().view(np.int32); xcc = raw[:, :, 6].copy().view(np.int32) & 15
-why = w[:, T + 1, wcols - 1].view(np.int32)
+why = w[:, wreg - 1].copy().view(np.int32)
 print('B=%d  fallbacks: %d' % (B, int((why != 0).sum())))
 for i, name in enumerate(['A chain ', 'B chain ', 'A helper', 'B helper']):
     m = st[:, i].mean(0)
     print('%s prologue %7.0f | phase0 %7.0f (%4.0f/step) | meet %6.0f | phase1 %7.0f (%4.0f/step) | tail %6.0f' % (
         name, m[0], m[1], m[1] / (T // 2), m[2], m[3], m[3] / (T - T // 2), m[4]))
 
-hsub = w[:, T, 32:48].reshape(B, 4, 4)
-for i in (2, 3):
-    print('helper role %d per iteration: sums+store %.0f (of which reads+adds %.0f) | emit %.0f | barrier %.0f' % (i, hsub[:, i, 0].mean() / (T - T // 2), hsub[:, i, 3].mean() / (T - T // 2), hsub[:, i, 1].mean() / (T - T // 2), hsub[:, i, 2].mean() / (T - T // 2)))
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
 from collections import Counter
