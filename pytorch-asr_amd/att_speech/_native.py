@@ -200,6 +200,7 @@ def _host_band_check(gm):
 # `_BAND_COOLDOWN` calls go to the log-domain kernel, which does not care.
 _BAND_STATE = {'cool': 0, 'pending': None}
 _BAND_COOLDOWN = 64
+_BAND_MAX_BATCH = 640          # utterances per launch up to which the band kernel is the faster one
 
 
 def _band_policy_allows():
@@ -253,10 +254,15 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
         ev0.record()
     # band lattices (CTC chains of mono-character transcripts): the linear-domain kernel
     # (ASR_LATTICE_BAND=0: the log-domain state-labelled kernel, for A/B runs)
-    band_env = os.environ.get('ASR_LATTICE_BAND', '1')        # 0: never, 2: always (no policy)
+    # ASR_LATTICE_BAND: 0 never, 2 always, 1 (default) by batch size and redo rate.  The band
+    # kernel keeps 2 chain + 2 helper waves per utterance (the log-domain kernel 8): up to two
+    # utterances per CU it is 25-30 % faster (B=512: 97 vs 123 us), with three per CU its two
+    # busy waves per utterance leave the SIMDs under-occupied in the first half and the 8-wave
+    # kernel is 7 % ahead (B=768: 150 vs 140 us)
+    band_env = os.environ.get('ASR_LATTICE_BAND', '1')
     use_band = (graph.band and band_env != '0' and
                 L.asr_lattice_fwbw_band_supported(T, B, C, graph.N, graph.Kin, graph.Kout, graph.Bg))
-    if use_band and band_env != '2' and not _band_policy_allows():
+    if use_band and band_env != '2' and (B > _BAND_MAX_BATCH or not _band_policy_allows()):
         use_band = False
     entry = L.asr_lattice_fwbw_band_f32 if use_band else L.asr_lattice_fwbw_f32
     check(entry(

@@ -71,6 +71,7 @@ def run_fwbw(lp, lens, mats, want_bwd=False, band=None):
         g.band = band
         if band:            # the kernel under test, whatever the redo-rate policy decided earlier
             _native._BAND_STATE.update(cool=0, pending=None)
+            _native._BAND_MAX_BATCH = 1 << 30
     logZ, grad, zb = _native.lattice_fwbw(
         torch.from_numpy(lp).to(d), torch.from_numpy(np.asarray(lens, np.int32)).to(d),
         g, -1e20, want_bwd_total=want_bwd)
