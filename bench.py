@@ -413,6 +413,13 @@ def dry_run(a, world, rank):
         dist.destroy_process_group()
 
 
+def mono_lattice_kernel(B):
+    """The kernel att_speech._native.lattice_fwbw launches for a mono-char CTC batch of B
+    utterances (band kernel up to _BAND_MAX_BATCH utterances, the state-labelled one above)."""
+    from att_speech import _native
+    return 'lattice_fwbw_band_kernel' if B <= _native._BAND_MAX_BATCH else 'lattice_fwbw_sl_kernel<3, 8, 1>'
+
+
 def pmc_traffic(order, B, T, kernel_tag=None):
     """HBM bytes per lattice launch from the PMC passes committed under profiles/
     (r03_pmc_step_fetch_write.json: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
@@ -423,7 +430,7 @@ def pmc_traffic(order, B, T, kernel_tag=None):
     the bi-char numerator launch of `roofline_bichar` is part of the same runs)."""
     if T != 1000:
         return None
-    k = kernel_tag or ('lattice_fwbw_band_kernel' if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>')
+    k = kernel_tag or mono_lattice_kernel(B) if order == 1 else kernel_tag or 'lattice_fwbw_sl_kernel<3, 8, 0>'
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_step_fetch_write.json')))
         if pmc.get('batch') != B:
@@ -617,7 +624,8 @@ def main():
                        'classes': C, 'parallelism': 'dp%d' % world,
                        'optimizer_steps': len(skipped) - sum(skipped),
                        'first_loss': loss0, 'final_loss': float(loss.detach())},
-            'roofline': {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan: lattice_fwbw_band_kernel for the mono-char chains)',
+            'roofline': {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan): %s' % (
+                             mono_lattice_kernel(B) if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>'),
                          'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': pmc_traffic(order, B, T),
                          'algorithmic_bytes_per_launch': alg,

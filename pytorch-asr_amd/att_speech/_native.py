@@ -75,17 +75,23 @@ _SIGNATURES = {
     'asr_lstm_dgrad_bf16': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'asr_lstm_wgrad_workspace_bytes': (_i64, [_i, _i, _i, _i]),
     'asr_lstm_wgrad_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
-    'asr_lstm_bidir_bwd_fused_bf16': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
-                                           _vp, _i64, _vp, _vp]),
     'asr_lstm_bidir_fwd_fused_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    'asr_lstm_bidir_fwd_fused_sum_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                               _vp, _vp]),
     'asr_bn_act_workspace_bytes': (_i64, [_i]),
     'asr_bn_act_fwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_bn_act_bwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
+
+# include/asr_amd_experiments.h: exported only by `make EXPERIMENTS=1` builds; bound when
+# present, never required (experiments_built() tells the callers).
+_EXPERIMENT_SIGNATURES = {
+    'asr_lstm_bidir_bwd_fused_bf16': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
+                                           _vp, _i64, _vp, _vp]),
+    'asr_lstm_bidir_fwd_fused_sum_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                               _vp, _vp]),
+}
+_experiments = False
 
 
 class NativeLibraryError(RuntimeError):
@@ -94,7 +100,7 @@ class NativeLibraryError(RuntimeError):
 
 def lib():
     """Load libasr_amd.so; fail loudly if it has not been built."""
-    global _lib
+    global _lib, _experiments
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise NativeLibraryError(
@@ -109,8 +115,27 @@ def lib():
         if handle.asr_abi_version() != ABI_VERSION:
             raise NativeLibraryError("libasr_amd.so ABI %d != expected %d" % (
                 handle.asr_abi_version(), ABI_VERSION))
+        _experiments = all(hasattr(handle, name) for name in _EXPERIMENT_SIGNATURES)
+        if _experiments:
+            for name, (res, args) in _EXPERIMENT_SIGNATURES.items():
+                fn = getattr(handle, name)
+                fn.restype = res
+                fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def experiments_built():
+    """True when libasr_amd.so was built with EXPERIMENTS=1 (include/asr_amd_experiments.h)."""
+    lib()
+    return _experiments
+
+
+def _need_experiments(what):
+    if not experiments_built():
+        raise NotImplementedError(
+            '%s is an experiment (include/asr_amd_experiments.h): rebuild with '
+            '`make -C pytorch-asr_amd/csrc clean all EXPERIMENTS=1`' % what)
 
 
 def check(code, what):
@@ -363,6 +388,22 @@ def _lstm_err_flag(device):
     return f
 
 
+def lstm_error_word(device):
+    """The device word a timed-out hand-off of the persistent recurrence sets (int32[1]), or None
+    when no recurrence has run on `device`; `dp.train_step` folds it into its one read-back."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _LSTM_ERR.get(idx)
+
+
+def lstm_raise_error(word):
+    word.zero_()
+    raise RuntimeError(
+        'persistent BiLSTM recurrence: a team hand-off timed out (another stream\'s kernel kept a '
+        'team mate off the device?); the outputs of that call, and the gradients of this step on '
+        'every rank, are NaN: the step is discarded. Set ASR_LSTM_PERSIST=0 to use one launch per '
+        'time step.')
+
+
 def lstm_check_errors():
     """Raise if a hand-off of the persistent BiLSTM recurrence timed out since the last
     check (csrc/lstm.hip team_wait: the kernel then poisons its outputs with NaN; the
@@ -404,6 +445,8 @@ def lstm_fused_supported(B, H, backward=False, F=None, dirsum=False):
     asr_lstm_bidir_bwd_fused_bf16 (bit 1) / asr_lstm_bidir_fwd_fused_sum_bf16 (bit 2, `dirsum`)
     run this (batch, hidden, input size)?"""
     F = H if F is None else F
+    if (dirsum or backward) and not experiments_built():
+        return False
     return bool(lib().asr_lstm_fused_supported(int(B), int(H), int(F)) & (4 if dirsum else 2 if backward else 1))
 
 
@@ -429,6 +472,7 @@ def lstm_bidir_fwd_fused(x_bf16, wih_bf16, whh_bf16, lens, want_y=True, want_sum
     nbytes = L.asr_lstm_workspace_bytes(B, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     if want_sum:
+        _need_experiments('asr_lstm_bidir_fwd_fused_sum_bf16')
         xsum = torch.empty((T, B, H), dtype=torch.bfloat16, device=dev)
         check(L.asr_lstm_bidir_fwd_fused_sum_bf16(_p(x_bf16), _p(wih_bf16), _p(whh_bf16), _p(lens), T, B, H, F,
                                                   _p(y), _p(ybf), _p(gates), _p(csave), _p(xsum), _p(ws), nbytes,
@@ -547,6 +591,7 @@ def lstm_bidir_bwd_fused(dy, whhT_bf16, wihT_bf16, lens, gates, csave, planes=Fa
     whhT_bf16 = _dev(whhT_bf16, torch.bfloat16, 'whhT')
     wihT_bf16 = _dev(wihT_bf16, torch.bfloat16, 'wihT')
     lens = _dev(lens, torch.int32, 'lens')
+    _need_experiments('asr_lstm_bidir_bwd_fused_bf16')
     mode, T, B = _dy_mode(dy, planes)
     H = dy.shape[-1]
     if tuple(wihT_bf16.shape) != (2, H, 4 * H) or tuple(whhT_bf16.shape) != (2, H, 4 * H):

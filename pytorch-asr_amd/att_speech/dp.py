@@ -5,10 +5,15 @@ One process per GPU.  Every rank holds a replica, runs forward/backward on its
 own shard of utterances (each shard re-sorted by length, descending, as the
 lattice scan requires) and the gradients are SUMMED across ranks with one
 all-reduce over a single flat fp32 bucket: the loss is a sum over utterances
-(advanced_decoder.py:524-527), so gradients add — no averaging.  Parameter
-gradients are views into the bucket, so backward writes straight into it and the
-collective needs no packing copy.  Backend: 'nccl' (= RCCL over xGMI on ROCm)
-for GPU tensors, 'gloo' in the CPU tests.
+(advanced_decoder.py:524-527), so gradients add — no averaging.  After backward
+the parameter gradients are gathered into the bucket with one multi-tensor copy
+(`FlatGradBucket.gather`: autograd accumulates into its own tensors) and from
+then on ARE views into it: clipping, the collective and the optimizer work on the
+flat buffer.  Backend: 'nccl' (= RCCL over xGMI on ROCm) for GPU tensors, 'gloo'
+in the CPU tests.  The all-reduce is NOT overlapped with backward: the persistent
+BiLSTM kernels need every workgroup of a team resident and nothing else on the
+device while they run (README "Limits"), so the collective follows the backward
+pass (0.4 ms of a 21 ms step at 27 MB over xGMI).
 """
 import torch
 import torch.distributed as dist
@@ -132,17 +137,35 @@ def train_step(model, optimizer, batch_args, hooks=(), bucket=None, current_iter
     else:
         optimizer.zero_grad()
     loss.backward()
+    err_word = None
+    if loss.is_cuda:
+        from att_speech import _native
+        err_word = _native.lstm_error_word(loss.device)     # device int32[1], None if no recurrence ran
     if bucket is not None:
         bucket.gather()
         bucket.all_reduce_sum(group)
+        if err_word is not None and dist.is_available() and dist.is_initialized() \
+                and dist.get_world_size(group) > 1:
+            # a timed-out hand-off poisons ONE rank's gradient with NaN, and the all-reduce has
+            # just spread it: every rank must learn of it and discard the step together
+            dist.all_reduce(err_word, op=dist.ReduceOp.MAX, group=group)
+    if err_word is not None:
+        # ONE read-back per step: the gradient norm the clipping hook wants and the error word
+        if bucket is not None:
+            pair = torch.stack([bucket.flat.norm(2), err_word[0].to(bucket.flat.dtype)]).tolist()
+            bucket.cached_norm = pair[0]
+            failed = pair[1] != 0
+        else:
+            failed = int(err_word.item()) != 0
+        if failed:
+            _native.lstm_raise_error(err_word)
     for h in hooks:
         if hasattr(h, 'bucket'):
             h.bucket = bucket
         skip = skip or bool(h.post_backward(model=model, optimizer=optimizer,
                                             current_iteration=current_iteration, loss=loss))
-    if loss.is_cuda:
-        from att_speech import _native
-        _native.lstm_check_errors()      # a timed-out hand-off left NaNs: raise before they reach the weights
+    if bucket is not None:
+        bucket.cached_norm = None
     if not skip:
         optimizer.step()
     for h in hooks:

@@ -44,7 +44,8 @@ def first_supported(conv, x):
             and conv.out_channels == 32 and tuple(conv.kernel_size) == (7, 7)
             and tuple(conv.stride) == (1, 2) and tuple(conv.padding) == (6, 0)
             and tuple(conv.dilation) == (1, 1) and x.dim() == 4 and x.size(1) == 1
-            and 7 <= x.size(3) and (x.size(3) - 7) // 2 + 1 <= 64)
+            and 7 <= x.size(3) and (x.size(3) - 7) // 2 + 1 <= 64
+            and not x.requires_grad)        # the kernel pair computes no feature gradient
 
 
 class Conv1Function(torch.autograd.Function):

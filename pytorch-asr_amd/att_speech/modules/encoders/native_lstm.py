@@ -22,6 +22,19 @@ def _mm_f32(a, b):
         return torch.mm(a, b).float()
 
 
+# byte offsets inside the persistent kernels are 32-bit (csrc/lstm.hip, lstm_fwd_impl): gates
+# [T,B,2,4H] f32-sized, the bf16 planes [2,T+2,B,H], the bf16 input [T,B,F]
+_FUSED_LIMITS = {'gates': 2 ** 32, 'planes': 2 ** 32, 'input': 2 ** 31}
+
+
+def _fused_fits(T, B, H, F):
+    """asr_lstm_fused_supported knows the tile shapes but not T: a long batch (B=768 with
+    T' >= 547 at H=320) exceeds the 32-bit offsets of the fused kernel, which then answers
+    ASR_EUNSUPPORTED; such batches take the GEMM + recurrence path instead."""
+    return (T * B * 8 * H * 4 < _FUSED_LIMITS['gates'] and 2 * (T + 2) * B * H * 2 < _FUSED_LIMITS['planes']
+            and T * B * F * 2 < _FUSED_LIMITS['input'])
+
+
 def _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, want_y, want_sum=False):
     """One layer's recurrence from its bf16 input [T*B, F].  Where the library has the fused
     kernel (F == H; or H = 320, F = 352 when the fp32 outputs are not wanted) the input
@@ -33,7 +46,7 @@ def _forward_layer(xb, w_ih, whh, lens_dev, T, B, H, want_y, want_sum=False):
     F = xb.shape[1]
     mode = os.environ.get('ASR_LSTM_FUSED', '1')         # 0: never, inner: only F == H layers
     if (mode != '0' and (F == H or (not want_y and mode != 'inner'))
-            and _native.lstm_fused_supported(B, H, F=F)):
+            and _native.lstm_fused_supported(B, H, F=F) and _fused_fits(T, B, H, F)):
         # want_sum + ASR_LSTM_DIRSUM=1: the direction sum on the bf16 planes comes out of the
         # recurrence itself (a fifth return value).  Opt-in: measured break-even at B=768 — the
         # second launch's set-up and the per-step tile fetch cost what the saved pass over the

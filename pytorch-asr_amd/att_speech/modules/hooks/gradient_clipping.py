@@ -51,7 +51,8 @@ class GradientClipping(TrainingLoopHook):
         if flat is None:
             return float(clip_grad_norm_(model.get_parameters_for_optimizer(), self.clip_norm))
         self.bucket.check_views()
-        norm = float(flat.norm(2))
+        cached = getattr(self.bucket, 'cached_norm', None)      # dp.train_step's single read-back
+        norm = float(flat.norm(2)) if cached is None else float(cached)
         scale = self.clip_norm / (norm + 1e-6)          # clip_grad_norm_'s rule
         if scale < 1:
             flat.mul_(scale)
@@ -60,6 +61,10 @@ class GradientClipping(TrainingLoopHook):
     def post_backward(self, model, optimizer, current_iteration, loss):
         norm = self._clip(model)
         too_large, skip = norm > self.clip_norm, norm > self.skip_step_norm
+        if not np.isfinite(norm):
+            # `nan > threshold` is False: the reference would step with NaN gradients; with a
+            # shared bucket one rank's NaN is everybody's after the all-reduce: skip the step
+            skip = True
         if self.gstats is None:
             self.gstats = _NormStats()
         self.gstats.add(norm, int(too_large), int(skip))

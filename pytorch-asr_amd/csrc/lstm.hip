@@ -1769,6 +1769,7 @@ extern "C" int asr_lstm_bidir_fwd_fused_bf16(const void *x_bf16, const void *wih
                          gates_bf16, csave, nullptr, workspace, workspace_bytes, err_flag, stream);
 }
 
+#ifdef ASR_EXPERIMENTS   // include/asr_amd_experiments.h: not in the default library
 // ... and xsum [T,B,H] bf16 = bf16(h_fwd) + bf16(h_rev), the next layer's input (BatchRNN's
 // direction merge, encoder_utils.py:112-117, on the bf16 planes): the recurrence runs as TWO
 // launches, steps [0, ceil(T/2)) and the rest; in the second every frame a direction reaches
@@ -1787,6 +1788,7 @@ extern "C" int asr_lstm_bidir_fwd_fused_sum_bf16(const void *x_bf16, const void 
     return lstm_fwd_impl(nullptr, 1, x_bf16, wih_bf16, F, whh_bf16, lens, T, B, H, y, y_bf16,
                          gates_bf16, csave, xsum_bf16, workspace, workspace_bytes, err_flag, stream);
 }
+#endif
 
 extern "C" int asr_lstm_fused_supported(int B, int H, int F) {
     if (!persist_enabled() || B <= 0) return 0;
@@ -1926,6 +1928,7 @@ extern "C" int asr_lstm_bidir_bwd_bf16(const float *dy, int dy_shared, const voi
                          dgates_bf16, nullptr, workspace, workspace_bytes, err_flag, stream);
 }
 
+#ifdef ASR_EXPERIMENTS   // include/asr_amd_experiments.h: not in the default library
 extern "C" int asr_lstm_bidir_bwd_fused_bf16(const float *dy, int dy_shared, const void *whhT_bf16,
                                              const void *wihT_bf16, const int32_t *lens,
                                              int T, int B, int H, const void *gates_bf16,
@@ -1936,6 +1939,7 @@ extern "C" int asr_lstm_bidir_bwd_fused_bf16(const float *dy, int dy_shared, con
     return lstm_bwd_impl(dy, dy_shared, whhT_bf16, wihT_bf16, lens, T, B, H, gates_bf16, csave,
                          dgates_bf16, dx, workspace, workspace_bytes, err_flag, stream);
 }
+#endif
 
 namespace {
 int lstm_bwd_impl(const float *dy, int dy_shared, const void *whhT_bf16, const void *wihT_bf16,

@@ -37,8 +37,8 @@ def test_algorithmic_bytes_and_synthetic_batch():
 
 def test_pmc_traffic_reads_the_committed_summary():
     b = load(os.path.join(ROOT, 'bench.py'), 'bench_mod2')
-    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_step_fetch_write.json')))
-    e = next(v for k, v in pmc['kernels'].items() if 'lattice_fwbw_sl_kernel<3, 8, 1>' in k)
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_step_fetch_write.json')))
+    e = next(v for k, v in pmc['kernels'].items() if b.mono_lattice_kernel(pmc['batch']) in k)
     want = (2 * e['fetch_KB'] + e['write_KB']) * 1024.0        # FETCH_SIZE x2: DESIGN.md §5
     assert b.pmc_traffic(1, pmc['batch'], 1000) == want
     assert b.pmc_traffic(1, pmc['batch'] + 1, 1000) is None     # measured shape only

@@ -7,8 +7,8 @@ import re
 from conftest import ROOT
 
 
-def _declared():
-    text = open(os.path.join(ROOT, 'include', 'asr_amd.h')).read()
+def _declared(header='asr_amd.h'):
+    text = open(os.path.join(ROOT, 'include', header)).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(asr_[a-z0-9_]+)\s*\(', text)))
 
@@ -23,6 +23,20 @@ def test_library_exports_every_declared_symbol():
     assert set(_native._SIGNATURES) == set(names)
     assert _native.lib().asr_abi_version() == _native.ABI_VERSION
     assert b'invalid' in _native.lib().asr_strerror(_native.ASR_EINVAL)
+
+
+def test_experiments_stay_out_of_the_default_library():
+    """include/asr_amd_experiments.h: variants that lost against the default path are exported
+    only by a `make EXPERIMENTS=1` build, all of them or none."""
+    from att_speech import _native
+    names = _declared('asr_amd_experiments.h')
+    assert set(names) == set(_native._EXPERIMENT_SIGNATURES)
+    assert not set(names) & set(_declared())
+    handle = ctypes.CDLL(_native.LIB_PATH)
+    have = [hasattr(handle, n) for n in names]
+    assert all(have) == _native.experiments_built() and (all(have) or not any(have))
+    if os.environ.get('ASR_EXPECT_EXPERIMENTS', '0') != '1':
+        assert not any(have), 'the default build must not export experiment entry points'
 
 
 def test_argument_checks_need_no_gpu():

@@ -111,3 +111,14 @@ def test_first_convolution_forward_and_weight_gradient(B, T, F):
 
 def F_conv(x, w):
     return F.conv2d(x, w, None, (1, 2), (6, 0))
+
+
+def test_first_conv_with_feature_gradients_stays_on_torch():
+    """asr_conv1_7x7s2_* computes no gradient for the features: features that require one
+     must not take the native path, which would silently drop it."""
+    from att_speech.modules.encoders import native_conv
+    dev = torch.device('cuda:0')
+    conv = torch.nn.Conv2d(1, 32, (7, 7), stride=(1, 2), padding=(6, 0)).to(dev)
+    x = torch.randn(2, 1, 50, 40, device=dev)
+    assert native_conv.first_supported(conv, x)
+    assert not native_conv.first_supported(conv, x.clone().requires_grad_())

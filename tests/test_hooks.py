@@ -113,3 +113,19 @@ def test_train_step_order_and_skip():
     _, skipped = train_step(m, opt, ((x,), {}), hooks=[GradientClipping(1e-3)], bucket=bucket)
     assert not skipped and abs(float(bucket.flat.norm()) - 1e-3) < 1e-6
     assert any(not torch.equal(p, b) for p, b in zip(m.parameters(), before))
+
+
+def test_gradient_clipping_skips_a_non_finite_norm():
+    """`nan > skip_step_norm` is False: the reference would take the optimizer step with NaN
+    gradients.  With data parallelism one rank's NaN (a timed-out LSTM hand-off) is in every
+    rank's bucket after the all-reduce, so a non-finite norm always skips the step."""
+    from att_speech.modules.hooks import GradientClipping
+
+    class M(torch.nn.Linear):
+        def get_parameters_for_optimizer(self):
+            return self.parameters()
+    m = M(3, 2)
+    for p in m.parameters():
+        p.grad = torch.full_like(p, float('nan'))
+    hook = GradientClipping(clip_norm=1.0, skip_step_norm=10.0)
+    assert hook.post_backward(model=m, optimizer=None, current_iteration=0, loss=None) is True
