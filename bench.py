@@ -436,6 +436,8 @@ def pmc_traffic(order, B, T, kernel_tag=None):
         if pmc.get('batch') != B:
             return None
         e = next(v for n, v in pmc['kernels'].items() if k in n)
+        if 'by_grid' in e:          # several problem sizes in the run: the largest launch is the measured one
+            e = e['by_grid'][max(e['by_grid'], key=int)]
         return (2 * e['fetch_KB'] + e['write_KB']) * 1024.0
     except (OSError, KeyError, ValueError, StopIteration, TypeError):
         return None

@@ -14,12 +14,18 @@ import os
 
 
 def collect(d, counter):
+    """kernel name -> [(grid size in work-items, counter value)] over the dispatches"""
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == counter:
-                acc[r['Kernel_Name']].append(float(r['Counter_Value']))
+                acc[r['Kernel_Name']].append((int(r.get('Grid_Size') or 0), float(r['Counter_Value'])))
     return acc
+
+
+def mean(pairs, grid=None):
+    v = [x for g, x in pairs if grid is None or g == grid]
+    return round(sum(v) / len(v), 1) if v else None
 
 
 def main():
@@ -33,8 +39,16 @@ def main():
     for k in sorted(set(fe) | set(wr)):
         name = k[:100]
         kernels[name] = {'dispatches': len(fe.get(k, wr.get(k))),
-                         'fetch_KB': round(sum(fe[k]) / len(fe[k]), 1) if k in fe else None,
-                         'write_KB': round(sum(wr[k]) / len(wr[k]), 1) if k in wr else None}
+                         'fetch_KB': mean(fe[k]) if k in fe else None,
+                         'write_KB': mean(wr[k]) if k in wr else None}
+        # one kernel launched on several problem sizes (the extra workloads of bench.py): the
+        # means above mix them; by_grid keeps them apart (key = work-items of the launch)
+        grids = sorted({g for g, _ in fe.get(k, [])} | {g for g, _ in wr.get(k, [])})
+        if len(grids) > 1:
+            kernels[name]['by_grid'] = {
+                str(g): {'dispatches': sum(1 for gg, _ in fe.get(k, wr.get(k)) if gg == g),
+                         'fetch_KB': mean(fe.get(k, []), g), 'write_KB': mean(wr.get(k, []), g)}
+                for g in grids}
     json.dump({'note': 'separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `%s` (B=%d); raw '
                        'counter means per dispatch in KB. On gfx950 FETCH_SIZE under-reports '
                        'coalesced 4 B/lane streams by 2x (calibration in DESIGN.md §5); WRITE_SIZE '
