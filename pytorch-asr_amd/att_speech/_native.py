@@ -265,9 +265,9 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
     logZ = torch.empty(B, dtype=torch.float32, device=lp.device)
     grad = torch.empty_like(lp)
     zb = torch.empty(B, dtype=torch.float32, device=lp.device) if want_bwd_total else None
-    if T * B * C * 4 >= 2 ** 31 and graph.N <= 512 and not _WARNED.get('fits32'):
+    if (T + 64) * B * C * 4 >= 2 ** 32 and graph.N <= 512 and not _WARNED.get('fits32'):
         _WARNED['fits32'] = True        # csrc/lattice.hip: 32-bit buffer offsets in the fast kernels
-        warnings.warn('lattice_fwbw: T*B*C*4 = %.2f GiB >= 2 GiB (e.g. bi-char CTC at B >= ~670): the '
+        warnings.warn('lattice_fwbw: T*B*C*4 = %.2f GiB >= 4 GiB (e.g. bi-char CTC at B >= ~1100): the '
                       'meet-in-the-middle kernels address with 32-bit offsets, this call runs the '
                       'generic (much slower) kernel; split the batch' % (T * B * C * 4 / 2.0 ** 30))
     nbytes = L.asr_lattice_fwbw_workspace_bytes(T, B, C, graph.N)

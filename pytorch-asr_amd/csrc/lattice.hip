@@ -1221,7 +1221,11 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     void (*kern)(FwbwParams);
     int nt;
     const size_t lds_mitm = (size_t)(4 * Npad + 4 * Cpad + 64) * sizeof(float);
-    const bool fits32 = (size_t)T * B * C * 4 < (1ull << 31) &&
+    // the scan addresses lp / grad through raw buffers with UNSIGNED 32-bit byte offsets
+    // (modular arithmetic, bounds-checked by the hardware against num_records): the tensor and
+    // the frames the prefetch may run past either end (+- 64 covers D + the half-step overrun)
+    // must stay below 4 GiB so that an overrun offset cannot wrap into the tensor
+    const bool fits32 = (size_t)(T + 64) * B * C * 4 < (1ull << 32) &&
                         (size_t)(T + 2) * B * round_up(N, 64) * 4 < (1ull << 30);
     if (N <= 512 && Kmax <= 4 && lds_mitm <= 160 * 1024 && fits32) {
         // state-labelled fast path; a workgroup whose graph fails the entry

@@ -592,6 +592,52 @@ def test_full_size_bichar_numerator_properties():
     np.testing.assert_allclose(-logZ, want, rtol=RTOL_LOSS)
 
 
+def test_bichar_numerator_above_two_gib_stays_on_the_fast_kernel():
+    """bi-char CTC at B = 768 per GPU: T' B C 4 = 2.46 GB > 2^31.  The state-labelled kernel
+    addresses lp / grad with unsigned 32-bit byte offsets (limit 4 GiB, csrc/lattice.hip), so
+    the batch stays on it; checked through the properties that do not need an oracle run of
+    this size — posteriors of a frame sum to one, zeros past the end, forward total ==
+    backward total — and against the SAME utterances run as small batches (whose offsets stay
+    below 2^31): logZ and posteriors of the first, a middle and the last utterances, i.e.
+    the ones whose bytes sit at both ends of the offset range."""
+    from att_speech import _native, fst_utils as P
+    d = dev()
+    B, T, S = 768, 334, 49
+    C = S * S
+    assert T * B * C * 4 > 2 ** 31
+    rng = np.random.default_rng(11)
+    lens = np.sort(np.array([T - (b % 32) for b in range(B)], np.int32))[::-1].copy()
+    llens = np.array([100 - 2 * (b % 16) for b in range(B)])
+    mono = rng.integers(2, 49, size=(B, 100))
+    prev = np.concatenate([np.zeros((B, 1), mono.dtype), mono[:, :-1]], 1)
+    labs = prev * S + mono
+    mats = P.CTCGraphGen(context_order=2, num_symbols=S).get_training_matrices_batch(labs, llens)
+    gen = torch.Generator(device=d).manual_seed(3)
+    lp = _native.log_softmax_fwd(torch.randn(T, B, C, device=d, generator=gen), C)
+    lens_d = torch.from_numpy(lens).to(d)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')              # the slow-kernel warning must not fire
+        logZ, grad, zb = _native.lattice_fwbw(lp, lens_d, _native.Graph(mats, d), -1e20, want_bwd_total=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(logZ).all() and (logZ > -1e19).all()
+    assert (zb - logZ).abs().max().item() < 1e-3 * logZ.abs().max().item()
+    rows = grad.sum(-1)                              # [T, B]
+    mask = torch.arange(T, device=d)[:, None] < lens_d[None, :]
+    # (log-domain fp32 at |alpha + beta| ~ 2700: one ulp of the exponent is 2.4e-4 of the posterior)
+    assert (rows[mask] - 1.0).abs().max().item() < 5e-3
+    assert not grad[~mask].any().item() and grad.min().item() >= 0.0
+    for sel in ([0, 1, 2, 3], [382, 383, 384, 385], [764, 765, 766, 767]):
+        idx = torch.tensor(sel, device=d)
+        sub = [m[sel] if m.shape[0] == B else m for m in mats]
+        z2, g2, _ = _native.lattice_fwbw(lp[:, idx].contiguous(), lens_d[idx], _native.Graph(sub, d), -1e20)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(logZ[idx].cpu().numpy(), z2.cpu().numpy(), rtol=1e-6)
+        assert (grad[:, idx] - g2).abs().max().item() <= 2e-5
+    del grad, lp
+    torch.cuda.empty_cache()
+
+
 def test_full_size_grouped_denominator_properties():
     """The CTC-G denominator (2401 states x 51 arcs, group-factored kernels) at T' = 334,
     B = 16: posteriors of a frame sum to one, zeros past the end, forward == backward total,
