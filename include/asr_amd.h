@@ -384,6 +384,19 @@ int asr_log_softmax_shift_bwd_f32(const float *y, const float *nls, const float 
 int asr_sum_leading_f32(const float *in, int G, int64_t n, float *out, void *stream);
 
 /*
+ * x = hi + lo, hi = bf16(x) (round to nearest even), lo = bf16(x - hi): the operands of the
+ * split-bf16 class projection of the decoders (advanced_decoder.py:79-223 computes
+ * `F.linear(frames, weight, bias)` in fp32; with C = 2401 classes the three bf16 MFMA products
+ * hi hi + hi lo + lo hi, accumulated in fp32, stand for it at 2^-16 relative error per term).
+ *   x [rows, cols] f32 with row stride ldx (elements); hi / lo [rows, cols] bf16 with row
+ *   strides ldhi / ldlo — strided so that the halves can be written straight into the
+ *   K-concatenated operand [rows, 3 cols].  A contiguous tensor is one row of n elements.
+ * (ABI v14)
+ */
+int asr_split_bf16_f32(const float *x, int64_t rows, int64_t cols, int64_t ldx,
+                       void *hi_bf16, int64_t ldhi, void *lo_bf16, int64_t ldlo, void *stream);
+
+/*
  * The 7x7, 32 -> 32 channel convolution of the DeepSpeech2 front-end (reference
  * att_speech/modules/encoders/deep_speech_2.py:60-73, Conv2d(32, 32, (7, 7), stride
  * (stride_h, 1)), stride_h in {1, 3}) on channels-last bf16 with fp32 accumulation, bias-free

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -56,6 +56,7 @@ _SIGNATURES = {
     'asr_log_softmax_shift_fwd_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_log_softmax_shift_bwd_f32': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     'asr_sum_leading_f32': (_i, [_vp, _i, _i64, _vp, _vp]),
+    'asr_split_bf16_f32': (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     'asr_tcn_attention_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                         _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_beam_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f,
@@ -901,6 +902,27 @@ def conv1_wgrad(x, dy):
     check(L.asr_conv1_7x7s2_wgrad(_p(x), _p(dy), B, T, F, _p(dw), _p(ws), nbytes, _stream()),
           'asr_conv1_7x7s2_wgrad')
     return dw
+
+
+def split_bf16(x, hi=None, lo=None):
+    """asr_split_bf16_f32: x f32 on the GPU -> (hi, lo) bf16 with hi + lo = x to 2^-16.
+    x contiguous of any shape (new contiguous outputs), or x [rows, cols] with given 2-D
+    output views hi / lo whose last dimension is dense (the halves of a K-concatenated
+    GEMM operand)."""
+    x = _dev(x, torch.float32, 'x')
+    if hi is None:
+        hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        rows, cols, ldx, ldh, ldl = 1, x.numel(), x.numel(), x.numel(), x.numel()
+    else:
+        if x.dim() != 2 or hi.shape != x.shape or lo.shape != x.shape or x.stride(1) != 1 \
+                or hi.stride(1) != 1 or lo.stride(1) != 1 or hi.dtype != torch.bfloat16 or lo.dtype != torch.bfloat16:
+            raise ValueError('split_bf16: x, hi, lo must be [rows, cols] with a dense last dimension')
+        rows, cols = x.shape
+        ldx, ldh, ldl = x.stride(0), hi.stride(0), lo.stride(0)
+    check(lib().asr_split_bf16_f32(_p(x), rows, cols, ldx, _p(hi), ldh, _p(lo), ldl, _stream()),
+          'asr_split_bf16_f32')
+    return hi, lo
 
 
 def sum_leading(t):

@@ -20,6 +20,8 @@ How it is organised is this build's own:
 """
 from __future__ import absolute_import, division, print_function
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -74,6 +76,103 @@ class _FrameProjection(torch.autograd.Function):
         return dy_r.matmul(weight).view_as(x), dweight, dbias
 
 
+_PROJ_KPAD = int(os.environ.get('ASR_PROJ_KPAD', '64'))     # extra K columns of the forward product (>= 2, multiple of 8)
+
+
+_WIDE_DW_CHUNKS = int(os.environ.get('ASR_PROJ_DW_CHUNKS', '16'))
+
+
+def _mm32(a, b):
+    """bf16 x bf16 -> fp32 library product (MFMA, fp32 accumulation)"""
+    return torch.mm(a, b, out_dtype=torch.float32)
+
+
+class _WideFrameProjection(torch.autograd.Function):
+    """The same product for a WIDE class layer (bi-character alphabets: C = 2401) as
+    split-bf16 MFMA products.  In fp32 the three products of a step (logits, dx, dW: 0.79
+    TFLOP at 171 k frames) run at the fp32 matrix rate and are a third of the bi-char step;
+    with x = xh + xl, W = Wh + Wl (bf16 halves, `_native.split_bf16`),
+        x Wt  ~  xh Wht + xh Wlt + xl Wht            (the xl Wlt term is 2^-16 of a 2^-8 term)
+    runs at the bf16 rate with fp32 accumulation and keeps 2^-16 relative error per product —
+    two orders below what the decoder's 1e-4 loss bound needs (tests/test_model_gpu.py holds
+    the C = 2401 steps to the fp32 CPU reference).  Forward: ONE product over the
+    K-concatenated operands [xh | xh | xl] [Wh | Wl | Wh]t (the sum happens in the MFMA
+    accumulator); backward: three products each for dx and dW, summed in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        rows, K = x.numel() // x.size(-1), x.size(-1)
+        C = weight.size(0)
+        # (the backward's dx products run on csrc/lstm_dgrad.hip when the shapes are the ones
+        # it is built for — [rows, 2560] x [2560, 320]: 2.6x the library's pick for them)
+        dgrad = K == 320 and C <= 2560 and _native.lstm_dgrad_supported(K) and rows * 5120 < 2 ** 31 - 2 ** 20
+        Cp = 2560 if dgrad else (C + 63) // 64 * 64
+        Kc = 3 * K + _PROJ_KPAD
+        x_r = x.reshape(rows, K)
+        # [xh | xh | xl | 1 1 0..0] x [Wh | Wl | Wh | bh bl 0..0]t: the bias rides in the product
+        # (a separate `y += b` is one more pass over the 1.6 GB of logits); 16 extra columns
+        # keep the rows 16-byte aligned for the library's fast kernels
+        a = torch.empty((rows, Kc), dtype=torch.bfloat16, device=x.device)
+        _native.split_bf16(x_r, a[:, :K], a[:, 2 * K:3 * K])
+        a[:, K:2 * K].copy_(a[:, :K])
+        a[:, 3 * K:3 * K + 2] = 1.0
+        a[:, 3 * K + 2:] = 0.0
+        # the halves of W, zero-padded to Cp rows: the backward products run over Cp (= 2432
+        # for 2401 classes) columns of dy — rows of 2401 bf16 are not 16-byte aligned and send
+        # the library to kernels three times slower
+        whp = torch.zeros((Cp, K), dtype=torch.bfloat16, device=x.device)
+        wlp = torch.zeros((Cp, K), dtype=torch.bfloat16, device=x.device)
+        _native.split_bf16(weight.detach(), whp[:C], wlp[:C])
+        wcat = torch.zeros((C, Kc), dtype=torch.bfloat16, device=x.device)
+        wcat[:, :K] = whp[:C]
+        wcat[:, K:2 * K] = wlp[:C]
+        wcat[:, 2 * K:3 * K] = whp[:C]
+        if bias is not None:
+            bh, bl = _native.split_bf16(bias.detach())
+            wcat[:, 3 * K] = bh
+            wcat[:, 3 * K + 1] = bl
+        y = _mm32(a, wcat.t())
+        ctx.save_for_backward(a, whp, wlp)
+        ctx.with_bias, ctx.xshape, ctx.C, ctx.dgrad = bias is not None, x.shape, C, dgrad
+        return y.view(x.shape[:-1] + (C,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, whp, wlp = ctx.saved_tensors
+        Cp, K = whp.shape
+        C, rows = ctx.C, a.size(0)
+        dy_r = dy.reshape(rows, C)
+        dbias = None
+        if ctx.with_bias:
+            g = _frame_chunks(rows)
+            dbias = dy_r.view(g, rows // g, -1).sum(1).sum(0)
+        dh = torch.empty((rows, Cp), dtype=torch.bfloat16, device=dy.device)
+        dl = torch.empty((rows, Cp), dtype=torch.bfloat16, device=dy.device)
+        if Cp > C:
+            dh[:, C:] = 0.0
+            dl[:, C:] = 0.0
+        _native.split_bf16(dy_r, dh[:, :C], dl[:, :C])
+        xh, xl = a[:, :K], a[:, 2 * K:3 * K]
+        if ctx.dgrad:
+            def mm(d, w):
+                return _native.lstm_dgrad(d.view(rows, 1, 2, Cp // 2), w).view(rows, K)
+        else:
+            mm = _mm32
+        dx = mm(dh, whp)
+        dx += mm(dh, wlp)
+        dx += mm(dl, whp)
+        # dW: a product over ALL frames into a small [C, K] output — as one library call it runs on
+        # ~20 workgroups (0.8 ms per term); split over G chunks of frames and summed
+        G = _WIDE_DW_CHUNKS if rows % _WIDE_DW_CHUNKS == 0 else 1
+        dh3, dl3 = dh.view(G, rows // G, Cp).transpose(1, 2), dl.view(G, rows // G, Cp).transpose(1, 2)
+        xh3, xl3 = xh.reshape(G, rows // G, K), xl.reshape(G, rows // G, K)
+        part = torch.bmm(dh3, xh3, out_dtype=torch.float32)
+        part += torch.bmm(dh3, xl3, out_dtype=torch.float32)
+        part += torch.bmm(dl3, xh3, out_dtype=torch.float32)
+        dweight = _native.sum_leading(part) if G > 1 else part[0]
+        return dx.view(ctx.xshape), dweight[:C], dbias
+
+
 def project_frames(layer, frames):
     """Apply a class-projection layer (`class_weight_bias()`) to `[..., F]` frames."""
     weight, bias = layer.class_weight_bias()
@@ -81,6 +180,10 @@ def project_frames(layer, frames):
         logger.log_scalar("ngram_linear_weight_norm", torch.norm(weight))
     many = frames.dim() >= 2 and frames.numel() // frames.size(-1) >= 4096
     if frames.is_cuda and many:
+        # ASR_PROJ_SPLIT=0: the fp32 products (A/B runs)
+        if (weight.size(0) > 256 and frames.dtype == torch.float32 and weight.dtype == torch.float32
+                and os.environ.get('ASR_PROJ_SPLIT', '1') != '0'):
+            return _WideFrameProjection.apply(frames, weight, bias)
         return _FrameProjection.apply(frames, weight, bias)
     return F.linear(frames, weight, bias)
 

@@ -255,6 +255,98 @@ extern "C" int asr_sum_leading_f32(const float *in, int G, int64_t n, float *out
 
 
 // -----------------------------------------------------------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): the operands of the split-bf16 class
+// projection (three bf16 MFMA products hi hi + hi lo + lo hi stand for one fp32 product,
+// relative error 2^-16 per term).  One pass: 4 bytes in, 2 + 2 out per element.
+namespace {
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_f32(unsigned short h) {
+    return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float *x, int64_t rows, int64_t cols, int64_t ldx,
+                                                         unsigned short *hi, int64_t ldhi,
+                                                         unsigned short *lo, int64_t ldlo, int vec) {
+    const int64_t q = (cols + 3) >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * q) return;
+    const int64_t r = i / q, c = (i - r * q) * 4;
+    const float *xp = x + r * ldx + c;
+    unsigned short *hp = hi + r * ldhi + c, *lp = lo + r * ldlo + c;
+    if (vec && c + 3 < cols) {
+        const float4 v = *reinterpret_cast<const float4 *>(xp);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = bf16_rne(f[k]);
+            l[k] = bf16_rne(f[k] - bf16_f32(h[k]));
+        }
+        *reinterpret_cast<uint2 *>(hp) = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+        *reinterpret_cast<uint2 *>(lp) = uint2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+    } else {
+        for (int k = 0; k < 4 && c + k < cols; ++k) {
+            const unsigned short h = bf16_rne(xp[k]);
+            hp[k] = h;
+            lp[k] = bf16_rne(xp[k] - bf16_f32(h));
+        }
+    }
+}
+// dense x (ldx == cols) whose rows are NOT 16-byte aligned (2401 classes): 16-byte loads over
+// the flat tensor, the four elements of a load find their own (row, column)
+__global__ __launch_bounds__(256) void split_bf16_flat_kernel(const float *x, int64_t n, int64_t cols,
+                                                              unsigned short *hi, int64_t ldhi,
+                                                              unsigned short *lo, int64_t ldlo) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    float f[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + i);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+        for (int k = 0; i + k < n; ++k) f[k] = x[i + k];
+    }
+    int64_t r = i / cols, c = i - r * cols;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i + k < n) {
+            const unsigned short h = bf16_rne(f[k]);
+            hi[r * ldhi + c] = h;
+            lo[r * ldlo + c] = bf16_rne(f[k] - bf16_f32(h));
+        }
+        if (++c == cols) { c = 0; ++r; }
+    }
+}
+}  // namespace
+
+extern "C" int asr_split_bf16_f32(const float *x, int64_t rows, int64_t cols, int64_t ldx,
+                                  void *hi_bf16, int64_t ldhi, void *lo_bf16, int64_t ldlo, void *stream) {
+    if (rows < 0 || cols < 0 || ldx < cols || ldhi < cols || ldlo < cols) return ASR_EINVAL;
+    if (rows == 0 || cols == 0) return ASR_OK;
+    if (!x || !hi_bf16 || !lo_bf16) return ASR_EINVAL;
+    const int64_t items = rows * ((cols + 3) >> 2);
+    if (items > (int64_t)0x7fffffff * 256) return ASR_EUNSUPPORTED;
+    // 16-byte loads / 8-byte stores when every row starts aligned
+    const int vec = ((ldx | ldhi | ldlo) & 3) == 0 && ((uintptr_t)x & 15) == 0 &&
+                    (((uintptr_t)hi_bf16 | (uintptr_t)lo_bf16) & 7) == 0;
+    if (!vec && ldx == cols && rows > 1 && ((uintptr_t)x & 15) == 0) {
+        const int64_t n = rows * cols, it = (n + 3) >> 2;
+        hipLaunchKernelGGL(split_bf16_flat_kernel, dim3((unsigned)((it + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, x, n, cols, (unsigned short *)hi_bf16, ldhi,
+                           (unsigned short *)lo_bf16, ldlo);
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, rows, cols, ldx, (unsigned short *)hi_bf16, ldhi, (unsigned short *)lo_bf16, ldlo, vec);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+
+// -----------------------------------------------------------------------------------------
 // Normalise + stabilise in one pass (FSTDecoder with normalize_by_dim = 0 and the row-max
 // stabilisation of advanced_decoder.py:479-484): log_softmax(x) - max_c log_softmax(x) is
 // x - max_c x — the normaliser cancels — so the shifted acts are written straight from the
