@@ -24,7 +24,10 @@ def main():
             for r in csv.DictReader(open(f)):
                 if match in r['Kernel_Name']:
                     key = (r['Kernel_Name'][:80], int(r.get('Grid_Size') or 0))
-                    dur[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3)
+                    try:
+                        dur[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3)
+                    except (KeyError, ValueError):
+                        pass
     res = []
     for key in sorted(vals):
         e = {'kernel': key[0], 'grid_work_items': key[1],
