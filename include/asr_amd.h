@@ -90,8 +90,12 @@ int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
  * only from {n, n-1, n-2} with arc weights <= 0, N <= 256, C <= 64, Bg == B — the lattices
  * CTCGraphGen builds for mono-character transcripts (fst_utils.py:603-613; the `2 L + 1`
  * CTC chain).  One wave per direction keeps four consecutive states per lane (no
- * transcendental, no LDS and no barrier on the recurrence), alpha / beta are rescaled by
- * exact powers of two, every posterior row is normalised by its own total.
+ * transcendental, no LDS and no barrier on the recurrence), alpha / beta are block floating
+ * point (one binary exponent per lane, rescaled by exact powers of two), every posterior row
+ * is normalised by its own total; only every second alpha / beta row goes through the
+ * workspace (the consumer recomputes the one in between).  The word behind the last
+ * utterance's workspace region (offset B * (T + 2) * (roundup(N, 64) + 64) floats) counts the
+ * utterances of the launch that were redone by the log-domain body.
  * asr_lattice_fwbw_band_supported says whether the SHAPES qualify; the graph of every
  * utterance is checked inside the kernel, and an utterance whose graph has another shape,
  * has no feasible alignment, or whose numbers leave the fp32 range runs the generic
