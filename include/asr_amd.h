@@ -380,6 +380,16 @@ int asr_log_softmax_shift_fwd_f32(const float *x, int T, int B, int C, const int
 int asr_log_softmax_shift_bwd_f32(const float *y, const float *nls, const float *dy, int64_t rows,
                                   int C, float *dx, void *stream);
 
+/* asr_log_softmax_shift_bwd_f32 for the split-bf16 class projection behind it (wide alphabets):
+ * the gradient leaves as dx = hi + lo, two bf16 tensors [rows, ld] (ld >= C, ld <= 2560; columns
+ * >= C zero) — the fp32 tensor is never written — together with its column sums (the
+ * projection's bias gradient) as asr_log_softmax_shift_bwd_split_blocks(rows) partial rows
+ * colsum_partial [blocks, ld], which the caller adds up (asr_sum_leading_f32).  (ABI v15) */
+int asr_log_softmax_shift_bwd_split_blocks(int64_t rows);
+int asr_log_softmax_shift_bwd_split_bf16(const float *y, const float *nls, const float *dy,
+                                         int64_t rows, int C, void *hi_bf16, void *lo_bf16, int ld,
+                                         float *colsum_partial, void *stream);
+
 /*
  * out[e] = sum over g < G of in[g * n + e] (n % 4 == 0): the sum of the partial products of a
  * weight-gradient GEMM split over chunks of frames (torch's strided reduction reads at

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -57,6 +57,8 @@ _SIGNATURES = {
     'asr_log_softmax_shift_bwd_f32': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     'asr_sum_leading_f32': (_i, [_vp, _i, _i64, _vp, _vp]),
     'asr_split_bf16_f32': (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
+    'asr_log_softmax_shift_bwd_split_blocks': (_i, [_i64]),
+    'asr_log_softmax_shift_bwd_split_bf16': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp]),
     'asr_tcn_attention_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                         _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'asr_beam_step_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f,
@@ -947,6 +949,24 @@ def log_softmax_shift_fwd(x, lens):
     check(lib().asr_log_softmax_shift_fwd_f32(_p(x), T, B, C, _p(lens), _p(y), _p(nls), _p(nls_sum),
                                               _stream()), 'asr_log_softmax_shift_fwd_f32')
     return y, nls, nls_sum
+
+
+def log_softmax_shift_bwd_split(y, nls, dy, ld):
+    """asr_log_softmax_shift_bwd_split_bf16: the gradient of log_softmax_shift_fwd as bf16
+    halves (hi, lo) [rows, ld] (columns >= C zero) and its column sums [C]."""
+    y, dy = _dev(y, torch.float32, 'y'), _dev(dy, torch.float32, 'dy')
+    C = y.shape[-1]
+    rows = y.numel() // C
+    L = lib()
+    hi = torch.empty((rows, ld), dtype=torch.bfloat16, device=y.device)
+    lo = torch.empty((rows, ld), dtype=torch.bfloat16, device=y.device)
+    part = torch.empty((L.asr_log_softmax_shift_bwd_split_blocks(rows), ld), dtype=torch.float32, device=y.device)
+    check(L.asr_log_softmax_shift_bwd_split_bf16(_p(y), _p(nls), _p(dy), rows, C, _p(hi), _p(lo), int(ld),
+                                                 _p(part), _stream()), 'asr_log_softmax_shift_bwd_split_bf16')
+    nb = part.shape[0]
+    if nb % 32 == 0 and nb > 32:         # two stages: sum_leading walks its leading axis serially
+        part = sum_leading(part.view(32, (nb // 32) * ld)).view(nb // 32, ld)
+    return hi, lo, sum_leading(part)[:C]
 
 
 def log_softmax_shift_bwd(y, nls, dy):

@@ -101,49 +101,19 @@ class _WideFrameProjection(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        rows, K = x.numel() // x.size(-1), x.size(-1)
-        C = weight.size(0)
-        # (the backward's dx products run on csrc/lstm_dgrad.hip when the shapes are the ones
-        # it is built for — [rows, 2560] x [2560, 320]: 2.6x the library's pick for them)
-        dgrad = K == 320 and C <= 2560 and _native.lstm_dgrad_supported(K) and rows * 5120 < 2 ** 31 - 2 ** 20
-        Cp = 2560 if dgrad else (C + 63) // 64 * 64
-        Kc = 3 * K + _PROJ_KPAD
-        x_r = x.reshape(rows, K)
-        # [xh | xh | xl | 1 1 0..0] x [Wh | Wl | Wh | bh bl 0..0]t: the bias rides in the product
-        # (a separate `y += b` is one more pass over the 1.6 GB of logits); 16 extra columns
-        # keep the rows 16-byte aligned for the library's fast kernels
-        a = torch.empty((rows, Kc), dtype=torch.bfloat16, device=x.device)
-        _native.split_bf16(x_r, a[:, :K], a[:, 2 * K:3 * K])
-        a[:, K:2 * K].copy_(a[:, :K])
-        a[:, 3 * K:3 * K + 2] = 1.0
-        a[:, 3 * K + 2:] = 0.0
-        # the halves of W, zero-padded to Cp rows: the backward products run over Cp (= 2432
-        # for 2401 classes) columns of dy — rows of 2401 bf16 are not 16-byte aligned and send
-        # the library to kernels three times slower
-        whp = torch.zeros((Cp, K), dtype=torch.bfloat16, device=x.device)
-        wlp = torch.zeros((Cp, K), dtype=torch.bfloat16, device=x.device)
-        _native.split_bf16(weight.detach(), whp[:C], wlp[:C])
-        wcat = torch.zeros((C, Kc), dtype=torch.bfloat16, device=x.device)
-        wcat[:, :K] = whp[:C]
-        wcat[:, K:2 * K] = wlp[:C]
-        wcat[:, 2 * K:3 * K] = whp[:C]
-        if bias is not None:
-            bh, bl = _native.split_bf16(bias.detach())
-            wcat[:, 3 * K] = bh
-            wcat[:, 3 * K + 1] = bl
-        y = _mm32(a, wcat.t())
-        ctx.save_for_backward(a, whp, wlp)
-        ctx.with_bias, ctx.xshape, ctx.C, ctx.dgrad = bias is not None, x.shape, C, dgrad
-        return y.view(x.shape[:-1] + (C,))
+        y, saved, meta = _wide_forward(x, weight, bias)
+        ctx.save_for_backward(*saved)
+        ctx.meta = meta
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         a, whp, wlp = ctx.saved_tensors
-        Cp, K = whp.shape
-        C, rows = ctx.C, a.size(0)
+        with_bias, xshape, C, dgrad = ctx.meta
+        Cp, rows = whp.size(0), a.size(0)
         dy_r = dy.reshape(rows, C)
         dbias = None
-        if ctx.with_bias:
+        if with_bias:
             g = _frame_chunks(rows)
             dbias = dy_r.view(g, rows // g, -1).sum(1).sum(0)
         dh = torch.empty((rows, Cp), dtype=torch.bfloat16, device=dy.device)
@@ -152,25 +122,109 @@ class _WideFrameProjection(torch.autograd.Function):
             dh[:, C:] = 0.0
             dl[:, C:] = 0.0
         _native.split_bf16(dy_r, dh[:, :C], dl[:, :C])
-        xh, xl = a[:, :K], a[:, 2 * K:3 * K]
-        if ctx.dgrad:
-            def mm(d, w):
-                return _native.lstm_dgrad(d.view(rows, 1, 2, Cp // 2), w).view(rows, K)
-        else:
-            mm = _mm32
-        dx = mm(dh, whp)
-        dx += mm(dh, wlp)
-        dx += mm(dl, whp)
-        # dW: a product over ALL frames into a small [C, K] output — as one library call it runs on
-        # ~20 workgroups (0.8 ms per term); split over G chunks of frames and summed
-        G = _WIDE_DW_CHUNKS if rows % _WIDE_DW_CHUNKS == 0 else 1
-        dh3, dl3 = dh.view(G, rows // G, Cp).transpose(1, 2), dl.view(G, rows // G, Cp).transpose(1, 2)
-        xh3, xl3 = xh.reshape(G, rows // G, K), xl.reshape(G, rows // G, K)
-        part = torch.bmm(dh3, xh3, out_dtype=torch.float32)
-        part += torch.bmm(dh3, xl3, out_dtype=torch.float32)
-        part += torch.bmm(dl3, xh3, out_dtype=torch.float32)
-        dweight = _native.sum_leading(part) if G > 1 else part[0]
-        return dx.view(ctx.xshape), dweight[:C], dbias
+        dx, dweight = _wide_backward(a, whp, wlp, dh, dl, C, dgrad)
+        return dx.view(xshape), dweight, dbias
+
+
+def _wide_forward(x, weight, bias):
+    """-> (logits [..., C] f32, tensors to save, (with_bias, x.shape, C, dgrad))"""
+    rows, K = x.numel() // x.size(-1), x.size(-1)
+    C = weight.size(0)
+    # (the backward's dx products run on csrc/lstm_dgrad.hip when the shapes are the ones
+    # it is built for — [rows, 2560] x [2560, 320]: 2.6x the library's pick for them)
+    dgrad = K == 320 and C <= 2560 and _native.lstm_dgrad_supported(K) and rows * 5120 < 2 ** 31 - 2 ** 20
+    Cp = 2560 if dgrad else (C + 63) // 64 * 64
+    Kc = 3 * K + _PROJ_KPAD
+    x_r = x.reshape(rows, K)
+    # [xh | xh | xl | 1 1 0..0] x [Wh | Wl | Wh | bh bl 0..0]t: the bias rides in the product
+    # (a separate `y += b` is one more pass over the 1.6 GB of logits); the extra columns
+    # keep the rows 16-byte aligned for the library's fast kernels
+    a = torch.empty((rows, Kc), dtype=torch.bfloat16, device=x.device)
+    _native.split_bf16(x_r, a[:, :K], a[:, 2 * K:3 * K])
+    a[:, K:2 * K].copy_(a[:, :K])
+    a[:, 3 * K:3 * K + 2] = 1.0
+    a[:, 3 * K + 2:] = 0.0
+    # the halves of W, zero-padded to Cp rows: the backward products run over Cp columns of
+    # dy — rows of 2401 bf16 are not 16-byte aligned and send the library to kernels three
+    # times slower
+    whp = torch.zeros((Cp, K), dtype=torch.bfloat16, device=x.device)
+    wlp = torch.zeros((Cp, K), dtype=torch.bfloat16, device=x.device)
+    _native.split_bf16(weight.detach(), whp[:C], wlp[:C])
+    wcat = torch.zeros((C, Kc), dtype=torch.bfloat16, device=x.device)
+    wcat[:, :K] = whp[:C]
+    wcat[:, K:2 * K] = wlp[:C]
+    wcat[:, 2 * K:3 * K] = whp[:C]
+    if bias is not None:
+        bh, bl = _native.split_bf16(bias.detach())
+        wcat[:, 3 * K] = bh
+        wcat[:, 3 * K + 1] = bl
+    y = _mm32(a, wcat.t())
+    return y.view(x.shape[:-1] + (C,)), (a, whp, wlp), (bias is not None, x.shape, C, dgrad)
+
+
+def _wide_backward(a, whp, wlp, dh, dl, C, dgrad):
+    """dx [rows, K], dW [C, K] from the halves dh + dl [rows, Cp] of the logits' gradient"""
+    Cp, K = whp.shape
+    rows = a.size(0)
+    xh, xl = a[:, :K], a[:, 2 * K:3 * K]
+    if dgrad:
+        def mm(d, w):
+            return _native.lstm_dgrad(d.view(rows, 1, 2, Cp // 2), w).view(rows, K)
+    else:
+        mm = _mm32
+    dx = mm(dh, whp)
+    dx += mm(dh, wlp)
+    dx += mm(dl, whp)
+    # dW: a product over ALL frames into a small [C, K] output — as one library call it runs on
+    # ~20 workgroups (0.8 ms per term); split over G chunks of frames and summed
+    G = _WIDE_DW_CHUNKS if rows % _WIDE_DW_CHUNKS == 0 else 1
+    dh3, dl3 = dh.view(G, rows // G, Cp).transpose(1, 2), dl.view(G, rows // G, Cp).transpose(1, 2)
+    xh3, xl3 = xh.reshape(G, rows // G, K), xl.reshape(G, rows // G, K)
+    part = torch.bmm(dh3, xh3, out_dtype=torch.float32)
+    part += torch.bmm(dh3, xl3, out_dtype=torch.float32)
+    part += torch.bmm(dl3, xh3, out_dtype=torch.float32)
+    dweight = _native.sum_leading(part) if G > 1 else part[0]
+    return dx, dweight[:C]
+
+
+class _WideProjectNormaliseShift(torch.autograd.Function):
+    """_WideFrameProjection followed by _NormaliseShift (FSTDecoder with normalize_by_dim = 0)
+    as ONE autograd node: the gradient of the logits never exists in fp32 —
+    asr_log_softmax_shift_bwd_split_bf16 writes its bf16 halves and its column sums (the bias
+    gradient) directly: one 1.6 GB write and the split pass's read of it less per step."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, lens_dev):
+        y, saved, meta = _wide_forward(x, weight, bias)
+        shifted, nls, nls_sum = _native.log_softmax_shift_fwd(y, lens_dev)
+        ctx.save_for_backward(shifted, nls, *saved)
+        ctx.meta = meta
+        ctx.mark_non_differentiable(nls_sum)
+        return shifted, nls_sum
+
+    @staticmethod
+    def backward(ctx, dshifted, _):
+        shifted, nls, a, whp, wlp = ctx.saved_tensors
+        with_bias, xshape, C, dgrad = ctx.meta
+        dh, dl, dbias = _native.log_softmax_shift_bwd_split(shifted, nls, dshifted.contiguous(), whp.size(0))
+        dx, dweight = _wide_backward(a, whp, wlp, dh, dl, C, dgrad)
+        return dx.view(xshape), dweight, (dbias if with_bias else None), None
+
+
+def _wide_applies(frames, weight):
+    return (frames.is_cuda and frames.dim() >= 2 and frames.numel() // frames.size(-1) >= 4096
+            and weight.size(0) > 256 and frames.dtype == torch.float32 and weight.dtype == torch.float32
+            and os.environ.get('ASR_PROJ_SPLIT', '1') != '0')
+
+
+def project_normalise_shift(layer, frames, lens_dev):
+    """`_NormaliseShift(project_frames(layer, frames), lens)`; one node for wide alphabets"""
+    weight, bias = layer.class_weight_bias()
+    if _wide_applies(frames, weight) and weight.size(0) <= 2560 and frames.dim() == 3:
+        if layer.training:
+            logger.log_scalar("ngram_linear_weight_norm", torch.norm(weight))
+        return _WideProjectNormaliseShift.apply(frames, weight, bias, lens_dev)
+    return None
 
 
 def project_frames(layer, frames):
@@ -180,9 +234,7 @@ def project_frames(layer, frames):
         logger.log_scalar("ngram_linear_weight_norm", torch.norm(weight))
     many = frames.dim() >= 2 and frames.numel() // frames.size(-1) >= 4096
     if frames.is_cuda and many:
-        # ASR_PROJ_SPLIT=0: the fp32 products (A/B runs)
-        if (weight.size(0) > 256 and frames.dtype == torch.float32 and weight.dtype == torch.float32
-                and os.environ.get('ASR_PROJ_SPLIT', '1') != '0'):
+        if _wide_applies(frames, weight):        # ASR_PROJ_SPLIT=0: the fp32 products (A/B runs)
             return _WideFrameProjection.apply(frames, weight, bias)
         return _FrameProjection.apply(frames, weight, bias)
     return F.linear(frames, weight, bias)
@@ -565,9 +617,12 @@ class FSTDecoder(_ProjectionDecoder):
         """`unnormalised`: `logits` are the raw acts of a decoder with normalize_by_dim = 0;
         normalisation and stabilisation then run as one pass"""
         gg = self.graph_generator
-        numerator = self._numerator_graphs(texts, text_lens, other_data_in_batch, logits.device)
-        lens_dev = _native.lens_on(encoded_lens, logits.device)
-        if unnormalised:
+        device = logits[0].device if isinstance(logits, tuple) else logits.device
+        numerator = self._numerator_graphs(texts, text_lens, other_data_in_batch, device)
+        lens_dev = _native.lens_on(encoded_lens, device)
+        if isinstance(logits, tuple):                 # (shifted, max_sum) of project_normalise_shift
+            shifted, max_sum = logits
+        elif unnormalised:
             shifted, max_sum = _NormaliseShift.apply(logits, lens_dev)   # (:444-452) + (:479-484)
         else:
             shifted, max_sum = _SubRowMax.apply(logits, lens_dev)        # (:479-484)
@@ -588,8 +643,11 @@ class FSTDecoder(_ProjectionDecoder):
     def forward(self, encoded, encoded_lens, texts, text_lens, spkids=None,
                 **other_data_in_batch):
         if self.normalize_by_dim == 0 and self.normalize_by_dim is not None and encoded.is_cuda:
-            losses = self.get_fst_loss(self.fc(encoded), encoded_lens, texts, text_lens,
-                                       other_data_in_batch, unnormalised=True)
+            # wide alphabets: projection + normalisation + stabilisation as one autograd node
+            fused = project_normalise_shift(self.embedder, encoded,
+                                            _native.lens_on(encoded_lens, encoded.device))
+            losses = self.get_fst_loss(fused if fused is not None else self.fc(encoded), encoded_lens,
+                                       texts, text_lens, other_data_in_batch, unnormalised=True)
         else:
             losses = self.get_fst_loss(self.logits(encoded, encoded_lens), encoded_lens,
                                        texts, text_lens, other_data_in_batch)

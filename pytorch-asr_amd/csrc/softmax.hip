@@ -418,7 +418,78 @@ __global__ void lsm_shift_bwd_kernel(const float *__restrict__ y, const float *_
         }
     }
 }
+
+// The same gradient handed to the split-bf16 class projection: dx = hi + lo as two bf16
+// tensors [rows, ld] (columns >= C zero) instead of fp32 — the fp32 tensor (1.6 GB at 2401
+// classes) is never written nor read back by a separate split pass — and the column sums of dx
+// (the projection's bias gradient) as one partial row per workgroup, summed by the caller.
+template <int PER>
+__global__ __launch_bounds__(256) void lsm_shift_bwd_split_kernel(
+    const float *__restrict__ y, const float *__restrict__ nls, const float *__restrict__ dy,
+    unsigned short *__restrict__ hi, unsigned short *__restrict__ lo, float *__restrict__ colsum,
+    int64_t rows, int C, int ld) {
+    __shared__ float red[4][PER * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    float cs[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) cs[i] = 0.f;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float *yr = y + r * C, *gr = dy + r * C;
+        const float off = nls[r];
+        float vy[PER], vg[PER];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * 64 + lane;
+            vy[i] = c < C ? yr[c] : -INFINITY;
+            vg[i] = c < C ? gr[c] : 0.f;
+            s += vg[i];
+        }
+        s = wave_sum(s);
+        unsigned short *hr = hi + r * ld, *lr = lo + r * ld;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * 64 + lane;
+            if (c < ld) {
+                const float d = c < C ? vg[i] - __expf(vy[i] + off) * s : 0.f;
+                const unsigned short h = bf16_rne(d);
+                hr[c] = h;
+                lr[c] = bf16_rne(d - bf16_f32(h));
+                cs[i] += d;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) red[wv][i * 64 + lane] = cs[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < ld; c += 256)
+        colsum[(int64_t)blockIdx.x * ld + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
 }  // namespace
+
+static int split_blocks(int64_t rows) {
+    const int64_t b = (rows + 3) / 4;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+extern "C" int asr_log_softmax_shift_bwd_split_blocks(int64_t rows) { return rows > 0 ? split_blocks(rows) : 0; }
+
+extern "C" int asr_log_softmax_shift_bwd_split_bf16(const float *y, const float *nls, const float *dy,
+                                                    int64_t rows, int C, void *hi_bf16, void *lo_bf16, int ld,
+                                                    float *colsum_partial, void *stream) {
+    if (rows < 0 || C <= 0 || ld < C) return ASR_EINVAL;
+    if (rows == 0) return ASR_OK;
+    if (!y || !nls || !dy || !hi_bf16 || !lo_bf16 || !colsum_partial) return ASR_EINVAL;
+    if (ld > 64 * 40) return ASR_EUNSUPPORTED;          // (the kernel's per-lane column count)
+    hipStream_t s = (hipStream_t)stream;
+    // PER covers the padded row (ld columns)
+#define CALL(P) hipLaunchKernelGGL(lsm_shift_bwd_split_kernel<P>, dim3(split_blocks(rows)), dim3(256), 0, s, y, nls, dy, \
+                                   (unsigned short *)hi_bf16, (unsigned short *)lo_bf16, colsum_partial, rows, C, ld)
+    DISPATCH_PER(ld, CALL);
+#undef CALL
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
 
 extern "C" int asr_log_softmax_shift_fwd_f32(const float *x, int T, int B, int C,
                                              const int32_t *lens, float *y, float *nls,

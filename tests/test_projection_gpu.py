@@ -58,3 +58,32 @@ def test_wide_projection_matches_fp64(rows, F, C, bias, monkeypatch):
         scale = w.abs().max().item()
         e_split, e_f32 = (a - w).abs().max().item(), (r - w).abs().max().item()
         assert e_split <= 4 * e_f32 + 4e-5 * scale, (name, e_split, e_f32, scale)
+
+
+@pytest.mark.parametrize('T,B,F,C,bias', [(40, 128, 320, 2401, True), (33, 130, 320, 2401, False), (50, 100, 64, 300, True)])
+def test_fused_projection_normalise_shift(T, B, F, C, bias):
+    """one autograd node (the logits' gradient leaves the normalisation's backward as bf16
+    halves + column sums) == projection node followed by the normalise/shift node"""
+    from att_speech import _native
+    from att_speech.modules.decoders import advanced_decoder as ad
+    d = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(T + C)
+    x = torch.randn(T, B, F, generator=g).to(d).requires_grad_(True)
+    layer = torch.nn.Linear(F, C, bias=bias).to(d)
+    layer.class_weight_bias = lambda: (layer.weight, layer.bias)
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g).sort(descending=True)[0].to(d, torch.int32)
+    dsh = torch.rand(T, B, C, generator=g).to(d)          # posteriors-like: non-negative
+    params = [p for p in (x, layer.weight, layer.bias) if p is not None]
+
+    def grads(fn):
+        for p in params:
+            p.grad = None
+        shifted, msum = fn()
+        shifted.backward(dsh)
+        return [shifted.detach(), msum.detach()] + [p.grad.clone() for p in params]
+
+    fused = grads(lambda: ad.project_normalise_shift(layer, x, lens))
+    plain = grads(lambda: ad._NormaliseShift.apply(ad.project_frames(layer, x), lens))
+    for name, a, b in zip(('shifted', 'max_sum', 'dx', 'dW', 'db'), fused, plain):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 3e-5 * scale + 1e-6, (name, (a - b).abs().max().item(), scale)
