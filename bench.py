@@ -97,12 +97,15 @@ def model_config(order=1, workload=None):
     return enc, dec
 
 
+FEATS = (40, 1)      # (feature bins, channels); --features wsj: (81, 3), the WSJ recipes' real shape
+
+
 def synthetic_batch(B, T, rank, order=1):
     """features N(0,1) [B,T,40,1]; saturating batch = all-T
     lengths (B > 16), YAML batch = T - 8b; labels uniform in [2,48],
     L_b = 100 - 2 (b mod 16)."""
     g = torch.Generator().manual_seed(1234 + rank)
-    feats = torch.randn(B, T, 40, 1, generator=g)
+    feats = torch.randn(B, T, FEATS[0], FEATS[1], generator=g)
     lens = torch.tensor([T if B > 16 else T - 8 * b for b in range(B)], dtype=torch.int32)
     llens = torch.tensor([100 - 2 * (b % 16) for b in range(B)], dtype=torch.int32)
     texts = torch.randint(2, S, (B, 100), generator=g, dtype=torch.int32)
@@ -121,15 +124,16 @@ def lattice_algorithmic_bytes(enc_lens, C, label_lens, n_arcs):
     return int((4 * tl * (3 * C + 2 * ns) + 24 * np.asarray(n_arcs, np.int64) + 4 * ns).sum())
 
 
-def step_flops(B, T, C, in_feats=40, H=320, layers=4):
+def step_flops(B, T, C, in_feats=None, H=320, layers=4):
     """Dense multiply-add flops of one training step (SURVEY.md §8d 'Algorithmic
     flops'): both convolutions, the 4 BiLSTM layers (input + recurrent products)
     and the class projection; training = 3 x forward (fwd, dgrad, wgrad)."""
+    in_feats, cin = (FEATS[0] if in_feats is None else in_feats), FEATS[1]
     t1 = T + 2 * 6 - 7 + 1                      # conv1: k 7x7, stride (1,2), pad (6,0)
     f1 = (in_feats - 7) // 2 + 1
     t2 = (t1 - 7) // 3 + 1                      # conv2: k 7x7, stride (3,1)
     f2 = f1 - 7 + 1
-    fwd = 2.0 * B * 32 * t1 * f1 * 49 + 2.0 * B * 32 * t2 * f2 * 32 * 49
+    fwd = 2.0 * B * 32 * t1 * f1 * 49 * cin + 2.0 * B * 32 * t2 * f2 * 32 * 49
     rnn_in = 32 * f2
     for l in range(layers):
         fwd += 2 * 2.0 * t2 * B * 4 * H * ((rnn_in if l == 0 else H) + H)
@@ -454,6 +458,9 @@ def main():
                          'tiles; 576 = the same grid with 24-row tiles, 7 %% fewer frames/s)')
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--order', type=int, default=1, help='1 mono-char CTC, 2 bi-char CTC')
+    ap.add_argument('--features', default='40x1', choices=['40x1', 'wsj'],
+                    help="40x1: the BASELINE metric's synthetic 40-dim fbank (default); wsj: 81 mel bins x 3 "
+                         "channels, the shape of the WSJ recipes' real features (egs/wsj/yamls/ctc.yaml:8-15)")
     ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS),
                     help='BASELINE config; default ctc (mono-char, the headline metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -487,6 +494,9 @@ def main():
 
     if a.workload:
         a.order = WORKLOADS[a.workload][0]
+    global FEATS
+    if a.features == 'wsj':
+        FEATS = (81, 3)
     B, T, order = a.batch, a.frames, a.order
     C = S ** order
     feats, lens, texts, llens = synthetic_batch(B, T, rank, order)
@@ -618,10 +628,10 @@ def main():
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'WSJ %s-char CTC (egs/wsj/yamls/%s.yaml shapes), DeepSpeech2 '
                                    'conv+4xBiLSTM-320 encoder + FSTDecoder, fwd+bwd+%sAdam, '
-                                   'synthetic 40-dim x %d-frame fbank'
+                                   'synthetic %d-dim x %d-channel x %d-frame fbank'
                                    % ('mono' if order == 1 else 'bi',
                                       a.workload or ('ctc' if order == 1 else 'ctc_bi'),
-                                      hook_txt, T),
+                                      hook_txt, FEATS[0], FEATS[1], T),
                        'batch_per_gpu': B, 'global_batch': B * world, 'frames': T,
                        'classes': C, 'parallelism': 'dp%d' % world,
                        'optimizer_steps': len(skipped) - sum(skipped),

@@ -447,6 +447,17 @@ int asr_conv1_7x7s2_fwd(const float *x, const float *w, int B, int T, int F, voi
 int asr_conv1_7x7s2_wgrad(const float *x, const void *dy, int B, int T, int F, float *dw,
                           void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The same first convolution for the WSJ recipes' real features: x [B, T, F, cin] f32 — the
+ * reference's bs x t x f x c layout (deep_speech_2.py:127), cin = 3 (static, delta,
+ * delta-delta; egs/wsj/yamls/ctc.yaml:8-15), F = 81 -> Fo = 38 — w [32, cin, 7, 7] f32, the
+ * same outputs.  Built for cin == 3 and even Fo <= 48 (ASR_EUNSUPPORTED otherwise); workspace
+ * asr_conv1c_7x7s2_workspace_bytes(cin).  (ABI v16) */
+int64_t asr_conv1c_7x7s2_workspace_bytes(int cin);
+int asr_conv1c_7x7s2_fwd(const float *x, const float *w, int B, int T, int F, int cin, void *y,
+                         double *chan_sums, void *workspace, int64_t workspace_bytes, void *stream);
+int asr_conv1c_7x7s2_wgrad(const float *x, const void *dy, int B, int T, int F, int cin,
+                           float *dw, void *workspace, int64_t workspace_bytes, void *stream);
+
 /*
  * One label step of the TCN / local-attention decoder for every live hypothesis
  * (replaces LocalAttention.forward, reference att_speech/modules/tcn.py:193-230, and the

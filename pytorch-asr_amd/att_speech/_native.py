@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -53,6 +53,9 @@ _SIGNATURES = {
     'asr_conv1_7x7s2_workspace_bytes': (_i64, []),
     'asr_conv1_7x7s2_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_conv1_7x7s2_wgrad': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    'asr_conv1c_7x7s2_workspace_bytes': (_i64, [_i]),
+    'asr_conv1c_7x7s2_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
+    'asr_conv1c_7x7s2_wgrad': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     'asr_log_softmax_shift_fwd_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_log_softmax_shift_bwd_f32': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     'asr_sum_leading_f32': (_i, [_vp, _i, _i64, _vp, _vp]),
@@ -874,35 +877,62 @@ def conv7x7c32_wgrad(x, dy, stride_h):
     return dw
 
 
+def conv1_supported(F, cin):
+    """shapes csrc/conv.hip has a first convolution for: one channel (any width up to Fo = 64),
+    or the WSJ recipes' 3 channels with an even output width"""
+    Fo = (F - 7) // 2 + 1
+    return F >= 7 and ((cin == 1 and Fo <= 64) or (cin == 3 and Fo <= 48 and Fo % 2 == 0))
+
+
 def conv1_fwd(x, weight, want_sums=False):
-    """asr_conv1_7x7s2_fwd: x [B, T, F] f32, weight [32, 1, 7, 7] f32 -> y logical
-    [B, 32, T + 6, (F - 7) // 2 + 1] channels-last bf16."""
+    """asr_conv1_7x7s2_fwd / asr_conv1c_7x7s2_fwd: x [B, T, F] or [B, T, F, cin] f32, weight
+    [32, cin, 7, 7] f32 -> y logical [B, 32, T + 6, (F - 7) // 2 + 1] channels-last bf16."""
     x = _dev(x, torch.float32, 'x')
     weight = _dev(weight, torch.float32, 'weight')
-    B, T, F = x.shape
+    cin = x.shape[3] if x.dim() == 4 else 1
+    B, T, F = x.shape[:3]
+    if tuple(weight.shape) != (32, cin, 7, 7):
+        raise ValueError('conv1_fwd: weight must be [32, %d, 7, 7]' % cin)
     y = torch.empty((B, 32, T + 6, (F - 7) // 2 + 1), dtype=torch.bfloat16, device=x.device,
                     memory_format=torch.channels_last)
     L = lib()
-    nbytes = L.asr_conv1_7x7s2_workspace_bytes()
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     sums = torch.empty((2, 32), dtype=torch.float64, device=x.device) if want_sums else None
-    check(L.asr_conv1_7x7s2_fwd(_p(x), _p(weight), B, T, F, _p(y), _p(sums), _p(ws), nbytes,
-                                _stream()), 'asr_conv1_7x7s2_fwd')
+    if cin == 1:
+        nbytes = L.asr_conv1_7x7s2_workspace_bytes()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(L.asr_conv1_7x7s2_fwd(_p(x), _p(weight), B, T, F, _p(y), _p(sums), _p(ws), nbytes,
+                                    _stream()), 'asr_conv1_7x7s2_fwd')
+    else:
+        nbytes = L.asr_conv1c_7x7s2_workspace_bytes(cin)
+        if nbytes < 0:
+            raise NotImplementedError('conv1_fwd: %d input channels' % cin)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(L.asr_conv1c_7x7s2_fwd(_p(x), _p(weight), B, T, F, cin, _p(y), _p(sums), _p(ws), nbytes,
+                                     _stream()), 'asr_conv1c_7x7s2_fwd')
     return (y, sums) if want_sums else y
 
 
 def conv1_wgrad(x, dy):
-    """asr_conv1_7x7s2_wgrad: x [B, T, F] f32, dy logical [B, 32, To, Fo] channels-last bf16
-    -> dw [32, 1, 7, 7] f32."""
+    """asr_conv1_7x7s2_wgrad / asr_conv1c_7x7s2_wgrad: x [B, T, F] or [B, T, F, cin] f32, dy
+    logical [B, 32, To, Fo] channels-last bf16 -> dw [32, cin, 7, 7] f32."""
     x = _dev(x, torch.float32, 'x')
     dy = _nhwc_bf16(dy, 'dy')[0]
-    B, T, F = x.shape
-    dw = torch.empty((32, 1, 7, 7), dtype=torch.float32, device=x.device)
+    cin = x.shape[3] if x.dim() == 4 else 1
+    B, T, F = x.shape[:3]
+    dw = torch.empty((32, cin, 7, 7), dtype=torch.float32, device=x.device)
     L = lib()
-    nbytes = L.asr_conv1_7x7s2_workspace_bytes()
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    check(L.asr_conv1_7x7s2_wgrad(_p(x), _p(dy), B, T, F, _p(dw), _p(ws), nbytes, _stream()),
-          'asr_conv1_7x7s2_wgrad')
+    if cin == 1:
+        nbytes = L.asr_conv1_7x7s2_workspace_bytes()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(L.asr_conv1_7x7s2_wgrad(_p(x), _p(dy), B, T, F, _p(dw), _p(ws), nbytes, _stream()),
+              'asr_conv1_7x7s2_wgrad')
+    else:
+        nbytes = L.asr_conv1c_7x7s2_workspace_bytes(cin)
+        if nbytes < 0:
+            raise NotImplementedError('conv1_wgrad: %d input channels' % cin)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(L.asr_conv1c_7x7s2_wgrad(_p(x), _p(dy), B, T, F, cin, _p(dw), _p(ws), nbytes, _stream()),
+              'asr_conv1c_7x7s2_wgrad')
     return dw
 
 

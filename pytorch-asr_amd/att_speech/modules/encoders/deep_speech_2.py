@@ -135,9 +135,9 @@ class DeepSpeech2(BaseEncoder):
             else:
                 if bf16 and self.native_conv and not getattr(self, '_warned_conv1', False):
                     self._warned_conv1 = True
-                    warnings.warn('DeepSpeech2: the first convolution is not the 1->32 7x7 stride-(1,2) '
-                                  'shape on gradient-free features csrc/conv.hip is built for (e.g. the '
-                                  '3-channel WSJ features); using torch / MIOpen for it')
+                    warnings.warn('DeepSpeech2: the first convolution is not a (1 or 3)->32 7x7 stride-(1,2) '
+                                  'shape on gradient-free features csrc/conv.hip is built for; using '
+                                  'torch / MIOpen for it')
                 x = run_conv(c1, features, with_bias=False, keep_bf16=True)
             x = bn_hardtanh(x, conv[1].batch_norm, conv[2], out_bf16=bf16, conv_bias=c1.bias,
                             chan_sums=sums1)

@@ -39,18 +39,21 @@ class Conv7x7C32Function(torch.autograd.Function):
 
 
 def first_supported(conv, x):
-    """Conv2d(1, 32, (7, 7), stride (1, 2), padding (6, 0)) on [B, 1, T, F] features"""
-    return (x.is_cuda and isinstance(conv, torch.nn.Conv2d) and conv.in_channels == 1
+    """Conv2d(cin, 32, (7, 7), stride (1, 2), padding (6, 0)) on [B, cin, T, F] features: one
+    channel (the synthetic 40-dim benchmark features), or the WSJ recipes' three (81 mel bins:
+    static, delta, delta-delta) with an even output width"""
+    return (x.is_cuda and isinstance(conv, torch.nn.Conv2d) and conv.in_channels in (1, 3)
             and conv.out_channels == 32 and tuple(conv.kernel_size) == (7, 7)
             and tuple(conv.stride) == (1, 2) and tuple(conv.padding) == (6, 0)
-            and tuple(conv.dilation) == (1, 1) and x.dim() == 4 and x.size(1) == 1
-            and 7 <= x.size(3) and (x.size(3) - 7) // 2 + 1 <= 64
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and x.dim() == 4 and x.size(1) == conv.in_channels
+            and _native.conv1_supported(x.size(3), conv.in_channels)
             and not x.requires_grad)        # the kernel pair computes no feature gradient
 
 
 class Conv1Function(torch.autograd.Function):
-    """features [B, T, F] f32 -> [B, 32, T + 6, Fo] channels-last bf16; the features need no
-    gradient, the weight gradient is asr_conv1_7x7s2_wgrad"""
+    """features [B, T, F] or [B, T, F, cin] f32 -> [B, 32, T + 6, Fo] channels-last bf16; the
+    features need no gradient, the weight gradient is asr_conv1{,c}_7x7s2_wgrad"""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -67,9 +70,12 @@ class Conv1Function(torch.autograd.Function):
 
 
 def conv1(features, conv):
-    """features logical [B, 1, T, F] (any strides) -> (conv(features) without the bias, its
+    """features logical [B, cin, T, F] (any strides; the reference's [B, T, F, cin] batches
+    arrive as a permuted view, deep_speech_2.py:127) -> (conv(features) without the bias, its
     channel sums [2, 32] f64 for the following BatchNorm)"""
-    return Conv1Function.apply(features[:, 0], conv.weight)
+    if features.size(1) == 1:
+        return Conv1Function.apply(features[:, 0], conv.weight)
+    return Conv1Function.apply(features.permute(0, 2, 3, 1), conv.weight)
 
 
 def conv7x7c32(x, conv):

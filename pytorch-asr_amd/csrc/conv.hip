@@ -104,7 +104,20 @@ inline int conv_cu_count() {
 __device__ __forceinline__ void chan_partial_sums(const __bf16 *oimg, int npix, float *red, float *partial) {
     const int tid = threadIdx.x, ch = tid & 31, grp = tid >> 5;
     float s = 0.f, q = 0.f;
-    for (int m = grp; m < npix; m += 8) {
+    // (eight reads in flight: one by one the loop pays an LDS round trip per pixel — 110 us of
+    // the 357 us forward kernel at 38-wide rows)
+    int m = grp;
+    for (; m + 56 < npix; m += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (float)oimg[(m + 8 * u) * CH + ch];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s += v[u];
+            q += v[u] * v[u];
+        }
+    }
+    for (; m < npix; m += 8) {
         const float v = (float)oimg[m * CH + ch];
         s += v;
         q += v * v;
@@ -1051,6 +1064,243 @@ __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float *p
     if (kt < KS && kf < KS) dw[(co * KS + kt) * KS + kf] = s;
 }
 
+
+// =========================================================================================
+// The same first convolution for CIN input channels in the reference's feature layout
+// x [B, T, F, CIN] fp32 (deep_speech_2.py:127 permutes bs x t x f x c to NCHW; the WSJ recipes
+// feed 81 mel bins x 3 channels — static, delta, delta-delta — egs/wsj/yamls/ctc.yaml:8-15):
+// Conv2d(CIN, 32, (7, 7), stride (1, 2), padding (6, 0)).  K = CIN x 64: the single-channel
+// scheme with one window image PER INPUT CHANNEL in LDS ([ci][row][fo] x 16 bytes) and 4 CIN
+// k-steps per 32 pixels; the weight gradient has 2 CIN tap tiles.  ROWS output rows per
+// chunk (8 for the 38-wide WSJ rows: 16 | ROWS * Fo, prefetch registers that fit).
+// =========================================================================================
+template <int CIN>
+__global__ void conv1c_pack_kernel(const float *w, __bf16 *out) {      // [CIN][4 k-steps][64][8]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CIN * 4 * 64 * 8) return;
+    const int j = i & 7, l = (i >> 3) & 63, s = (i >> 9) & 3, ci = i >> 11;
+    const int kt = 2 * s + (l >> 5), kf = j, co = l & 31;
+    out[i] = (kt < KS && kf < KS) ? (__bf16)w[((co * CIN + ci) * KS + kt) * KS + kf] : (__bf16)0.f;
+}
+
+// Staging.  The chunk's input rows t0-6 .. t0-6+nrows-1 are ONE contiguous piece of x
+// (nrows * F * CIN floats): coalesced loads (RPT per thread, prefetchable into registers),
+// de-interleaved into bf16 planes [ci][row][FP] in LDS (FP >= 2 (Fo-1) + 8 columns, the ones
+// past F zero: for odd F the last window's 8th sample — zero weight — lies outside the row),
+// from which the window image [ci][row][fo] x 8 samples is built LDS -> LDS.  (Gathering the
+// windows straight from global memory — 8 strided loads per window — ran at 1.4 TB/s.)
+template <int CIN, int RPT>
+__device__ __forceinline__ void conv1c_raw_load(const Conv1Params &p, const float *xb, int t0, int nrows,
+                                                int tid, float (&r)[RPT]) {
+    const int FC = p.F * CIN;
+    const unsigned mg = ((1u << 24) + (unsigned)FC - 1u) / (unsigned)FC;   // e / FC = (e * mg) >> 24 for e < 2^13 (host)
+    const float *base = xb + (ptrdiff_t)(t0 - 6) * FC;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int e = tid + 256 * k;
+        const int t = t0 - 6 + (int)(((unsigned)e * mg) >> 24);
+        r[k] = (e < nrows * FC && t >= 0 && t < p.T) ? base[e] : 0.f;
+    }
+}
+template <int CIN, int RPT>
+__device__ __forceinline__ void conv1c_raw_stash(const Conv1Params &p, int nrows, int FP, int tid,
+                                                 const float (&r)[RPT], __bf16 *planes) {
+    const int FC = p.F * CIN;
+    const unsigned mg = ((1u << 24) + (unsigned)FC - 1u) / (unsigned)FC;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int e = tid + 256 * k;
+        if (e < nrows * FC) {
+            const int row = (int)(((unsigned)e * mg) >> 24), rem = e - row * FC, f = rem / CIN, ci = rem - f * CIN;
+            planes[(ci * nrows + row) * FP + f] = (__bf16)r[k];
+        }
+    }
+    for (int i = tid; i < CIN * nrows * (FP - p.F); i += 256) {       // the pad columns
+        const int rp = i / (FP - p.F), f = p.F + (i - rp * (FP - p.F));
+        planes[rp * FP + f] = (__bf16)0.f;
+    }
+}
+template <int CIN>
+__device__ __forceinline__ void conv1c_build_windows(int nrows, int Fo, int FP, int tid,
+                                                     const __bf16 *planes, char *wimg) {
+    const unsigned fmagic = (1u << 20) / (unsigned)Fo + 1u;
+    for (int i = tid; i < CIN * nrows * Fo; i += 256) {
+        const unsigned rp = ((unsigned)i * fmagic) >> 20, fo = (unsigned)i - rp * (unsigned)Fo;   // rp = ci * nrows + row
+        const unsigned *src = reinterpret_cast<const unsigned *>(planes + (size_t)rp * FP + 2 * fo);
+        u32x4 v;
+        v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+        *reinterpret_cast<u32x4 *>(wimg + (size_t)i * 16) = v;
+    }
+}
+
+// Persistent: a workgroup walks chunks (utterance, ROWS output rows) with the NEXT chunk's input
+// rows prefetched into registers while the current one is multiplied — one workgroup per chunk
+// left every chunk's global round trip exposed (531 us at B = 256 x 1000 frames; with three
+// workgroups per CU nothing else covers it).
+template <int CIN, int ROWS, int RPT>
+__global__ __launch_bounds__(256) void conv1c_fwd_kernel(Conv1Params p) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Fo = p.Fo;
+    const int npix = ROWS * Fo, ntiles = (npix + 31) >> 5, nwin1 = (ROWS + 8) * Fo;
+    const int FP = (2 * (Fo - 1) + 8 + 3) & ~3;
+    char *wimg = smem;                                         // [CIN][ROWS + 8][Fo] windows
+    __bf16 *oimg = reinterpret_cast<__bf16 *>(smem + (size_t)CIN * nwin1 * 16);   // [ntiles*32][32]
+    __bf16 *planes = oimg;                                     // (dead before the first output is written)
+    const unsigned fmagic = (1u << 20) / (unsigned)Fo + 1u;
+    bf16x8 bw[CIN * 4];
+#pragma unroll
+    for (int k = 0; k < CIN * 4; ++k) bw[k] = reinterpret_cast<const bf16x8 *>(p.wpack)[k * 64 + lane];
+    const int chunks_per_utt = (p.To + ROWS - 1) / ROWS;
+    const int nchunks = p.B * chunks_per_utt;
+    float rreg[RPT];
+    auto fetch = [&](int c) {
+        const int b = c / chunks_per_utt, t0 = (c - b * chunks_per_utt) * ROWS;
+        conv1c_raw_load<CIN, RPT>(p, p.x + (size_t)b * p.T * p.F * CIN, t0, ROWS + 8, tid, rreg);
+    };
+    if ((int)blockIdx.x < nchunks) fetch(blockIdx.x);
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int b = c / chunks_per_utt, t0 = (c - b * chunks_per_utt) * ROWS;
+        __syncthreads();                // the previous chunk's output image has left LDS
+        conv1c_raw_stash<CIN, RPT>(p, ROWS + 8, FP, tid, rreg, planes);
+        __syncthreads();
+        if (c + (int)gridDim.x < nchunks) fetch(c + gridDim.x);
+        conv1c_build_windows<CIN>(ROWS + 8, Fo, FP, tid, planes, wimg);
+        __syncthreads();
+        for (int tile = wave; tile < ntiles; tile += 4) {
+            int m = 32 * tile + (lane & 31);
+            if (m >= npix) m = npix - 1;
+            const unsigned r = ((unsigned)m * fmagic) >> 20, fo = (unsigned)m - r * (unsigned)Fo;
+            const char *base = wimg + (size_t)((r + (unsigned)(lane >> 5)) * (unsigned)Fo + fo) * 16;
+            f32x16 acc = {};
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(base + (size_t)(ci * nwin1 + 2 * s4 * Fo) * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[ci * 4 + s4], a, acc, 0, 0, 0);
+                }
+            // (tiles are written where the planes were: every wave is past the window build)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 o4 = {(__bf16)acc[4 * g], (__bf16)acc[4 * g + 1], (__bf16)acc[4 * g + 2], (__bf16)acc[4 * g + 3]};
+                *reinterpret_cast<bf16x4 *>(reinterpret_cast<char *>(oimg) + (size_t)(32 * tile + (lane & 31)) * 64 +
+                                            16 * g + 8 * (lane >> 5)) = o4;
+            }
+        }
+        __syncthreads();
+        const int rows_here = (p.To - t0) < ROWS ? (p.To - t0) : ROWS;
+        char *yb = reinterpret_cast<char *>(p.y) + ((size_t)b * p.To + t0) * Fo * 64;
+        for (int cc = tid; cc < rows_here * Fo * 4; cc += 256)
+            *reinterpret_cast<u32x4 *>(yb + (size_t)cc * 16) =
+                *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(oimg) + (size_t)cc * 16);
+        if (p.partial)
+            chan_partial_sums(oimg, rows_here * Fo, reinterpret_cast<float *>(oimg + (size_t)ntiles * 32 * CH),
+                              p.partial + (size_t)c * 64);
+    }
+}
+
+// weight gradient: M = co, N = CIN x 64 taps (2 CIN tiles), K = the ROWS * Fo pixels of a chunk
+template <int CIN, int ROWS, int DI, int RPT>
+__global__ __launch_bounds__(256) void conv1c_wgrad_kernel(Conv1Params p) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Fo = p.Fo, npix = ROWS * Fo, nks = npix >> 4;               // 16 | npix (host)
+    const int nwin1 = (ROWS + 8) * Fo;
+    const int FP = (2 * (Fo - 1) + 8 + 3) & ~3;
+    char *wimg = smem;                                                    // [CIN][ROWS + 8][Fo] windows
+    char *dimg = smem + (size_t)CIN * nwin1 * 16;                         // [npix] pixels x 80 B
+    __bf16 *planes = reinterpret_cast<__bf16 *>(dimg + (size_t)npix * PIX);   // [CIN][ROWS + 8][FP]
+    f32x16 acc[2 * CIN];
+#pragma unroll
+    for (int t = 0; t < 2 * CIN; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    const int h = lane >> 5, q = (lane & 15) >> 2, pp = lane & 3, chalf = (lane >> 4) & 1;
+    const unsigned a_off = (unsigned)((8 * h + q) * PIX + (16 * chalf + 4 * pp) * 2);
+    const int ktl = 2 * chalf + (pp >> 1);
+    const unsigned b_lane = (unsigned)(8 * (pp & 1));
+    const int chunks_per_utt = (p.To + ROWS - 1) / ROWS;
+    const int nchunks = p.B * chunks_per_utt;
+    const unsigned fmagic = (1u << 20) / (unsigned)Fo + 1u;
+    u32x4 dreg[DI];
+    float rreg[RPT];
+    auto fetch = [&](int c) {
+        const int b = c / chunks_per_utt, t0 = (c - b * chunks_per_utt) * ROWS;
+        const char *yb = reinterpret_cast<const char *>(p.y) + ((size_t)b * p.To + t0) * Fo * 64;
+        const int rows_here = (p.To - t0) < ROWS ? (p.To - t0) : ROWS;
+#pragma unroll
+        for (int k = 0; k < DI; ++k) {
+            const int i = tid + 256 * k, pix = i >> 2;
+            dreg[k] = pix < rows_here * Fo ? *reinterpret_cast<const u32x4 *>(yb + (size_t)i * 16) : u32x4{0u, 0u, 0u, 0u};
+        }
+        conv1c_raw_load<CIN, RPT>(p, p.x + (size_t)b * p.T * p.F * CIN, t0, ROWS + 8, tid, rreg);
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int k = 0; k < DI; ++k) {
+            const int i = tid + 256 * k, pix = i >> 2, part = i & 3;
+            if (pix < npix) *reinterpret_cast<u32x4 *>(dimg + pix * PIX + part * 16) = dreg[k];
+        }
+        conv1c_raw_stash<CIN, RPT>(p, ROWS + 8, FP, tid, rreg, planes);
+    };
+    if ((int)blockIdx.x < nchunks) fetch(blockIdx.x);
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        __syncthreads();                // the previous chunk's MFMAs are done with LDS
+        stash();
+        __syncthreads();
+        if (c + (int)gridDim.x < nchunks) fetch(c + gridDim.x);
+        conv1c_build_windows<CIN>(ROWS + 8, Fo, FP, tid, planes, wimg);
+        __syncthreads();
+        for (int ks = wave; ks < nks; ks += 4) {
+            const bf16x8 a = tr_frag(dimg + (size_t)(16 * ks) * PIX + a_off);
+            const unsigned p0 = (unsigned)(16 * ks + 8 * h + q), p1 = p0 + 4;
+            const unsigned r0 = (p0 * fmagic) >> 20, f0 = p0 - r0 * (unsigned)Fo;
+            const unsigned r1 = (p1 * fmagic) >> 20, f1 = p1 - r1 * (unsigned)Fo;
+#pragma unroll
+            for (int nt = 0; nt < 2 * CIN; ++nt) {
+                const int kt = 4 * (nt & 1) + ktl;
+                const char *plane = wimg + (size_t)(nt >> 1) * nwin1 * 16;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4 *)(plane + (size_t)((r0 + kt) * Fo + f0) * 16 + b_lane));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4 *)(plane + (size_t)((r1 + kt) * Fo + f1) * 16 + b_lane));
+                s16x8 v;
+                v.s0 = lo.x; v.s1 = lo.y; v.s2 = lo.z; v.s3 = lo.w;
+                v.s4 = hi.x; v.s5 = hi.y; v.s6 = hi.z; v.s7 = hi.w;
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, v), acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    // the four waves' sums, one tap tile at a time -> one partial image per workgroup
+    float *red = reinterpret_cast<float *>(smem);                         // [4][16][64]
+    float *out = p.partial + (size_t)blockIdx.x * 2 * CIN * 1024;
+#pragma unroll
+    for (int nt = 0; nt < 2 * CIN; ++nt) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[(wave * 16 + j) * 64 + lane] = acc[nt][j];
+        __syncthreads();
+        for (int e = tid; e < 1024; e += 256)
+            out[nt * 1024 + e] = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(1024) void conv1c_wgrad_reduce_kernel(const float *partial, int nparts, float *dw) {
+    __shared__ float lds4[1024];
+    const float s = partial_sum(partial, nparts, 2 * CIN * 1024, lds4);
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (threadIdx.x >= 64) return;
+    const int nt = e >> 10, j = (e >> 6) & 15, l = e & 63;
+    const int ci = nt >> 1;
+    const int co = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5), tap = 32 * (nt & 1) + (l & 31);
+    const int kt = tap >> 3, kf = tap & 7;
+    if (kt < KS && kf < KS) dw[((co * CIN + ci) * KS + kt) * KS + kf] = s;
+}
+
 }  // namespace
 
 
@@ -1301,5 +1551,82 @@ extern "C" int asr_conv1_7x7s2_wgrad(const float *x, const void *dy, int B, int 
                               : (di <= 8 && wpt <= 3 ? conv1_wgrad_kernel<8, 3> : conv1_wgrad_kernel<16, 6>);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, p);
     hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(2 * 1024 / 64), dim3(1024), 0, s, p.partial, nwg, dw);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+
+// ---- first convolution with CIN input channels (x [B, T, F, CIN]) -------------------------
+extern "C" int64_t asr_conv1c_7x7s2_workspace_bytes(int cin) {
+    if (cin != 3) return -1;
+    // packed weights + max(weight-gradient partials: 1024 workgroups x 2 cin tiles, channel sums)
+    const int64_t wg = (int64_t)C1_WGS * 2 * cin * 1024 * 4, cs = (int64_t)(1 << 17) * 64 * 4;
+    return (int64_t)cin * 4 * 64 * 8 * 2 + (wg > cs ? wg : cs) + 256;
+}
+
+extern "C" int asr_conv1c_7x7s2_fwd(const float *x, const float *w, int B, int T, int F, int cin, void *y,
+                                    double *chan_sums, void *workspace, int64_t workspace_bytes,
+                                    void *stream) {
+    int To, Fo;
+    const int rc = conv1_shapes(B, T, F, &To, &Fo);
+    if (rc != ASR_OK) return rc;
+    if (cin != 3 || (Fo & 1)) return ASR_EUNSUPPORTED;
+    if (!x || !w || !y || !workspace || workspace_bytes < asr_conv1c_7x7s2_workspace_bytes(cin))
+        return ASR_EINVAL;
+    if ((int64_t)T * F * cin * 4 * B >= (1ll << 40)) return ASR_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    __bf16 *wpack = (__bf16 *)workspace;
+    hipLaunchKernelGGL(conv1c_pack_kernel<3>, dim3(3 * 8), dim3(256), 0, s, w, wpack);
+    Conv1Params p;
+    p.x = x; p.wpack = wpack; p.y = (__bf16 *)y;
+    p.B = B; p.T = T; p.F = F; p.To = To; p.Fo = Fo;
+    constexpr int ROWS = 8;
+    const int64_t nchunks = (int64_t)B * ((To + ROWS - 1) / ROWS);
+    if (nchunks >= (1ll << 31)) return ASR_EUNSUPPORTED;
+    const dim3 grid((unsigned)(nchunks < 768 ? nchunks : 768));       // three workgroups per CU (LDS)
+    p.partial = chan_sums ? (float *)((char *)workspace + 3 * 4 * 64 * 8 * 2) : nullptr;
+    if (chan_sums && nchunks * 64 * 4 > (int64_t)(1 << 17) * 64 * 4) return ASR_EUNSUPPORTED;
+    const int ntiles = (ROWS * Fo + 31) / 32;
+    const int FP = (2 * (Fo - 1) + 8 + 3) & ~3;
+    size_t otail = (size_t)ntiles * 32 * CH * 2 + 512 * 4;
+    if (otail < (size_t)3 * (ROWS + 8) * FP * 2) otail = (size_t)3 * (ROWS + 8) * FP * 2;      // the planes alias it
+    const size_t lds = (size_t)3 * (ROWS + 8) * Fo * 16 + otail;
+    const int rpt = ((ROWS + 8) * F * 3 + 255) / 256;
+    if (lds > 64 * 1024 || rpt > 24) return ASR_EUNSUPPORTED;
+    if (rpt <= 16) hipLaunchKernelGGL((conv1c_fwd_kernel<3, ROWS, 16>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv1c_fwd_kernel<3, ROWS, 24>), grid, dim3(256), lds, s, p);
+    if (chan_sums) {
+        hipLaunchKernelGGL(zero_chan_sums_kernel, dim3(1), dim3(64), 0, s, chan_sums);
+        hipLaunchKernelGGL(chan_sums_reduce_kernel, dim3(64), dim3(1024), 0, s, p.partial, (int)nchunks, chan_sums);
+    }
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_conv1c_7x7s2_wgrad(const float *x, const void *dy, int B, int T, int F, int cin,
+                                      float *dw, void *workspace, int64_t workspace_bytes,
+                                      void *stream) {
+    int To, Fo;
+    const int rc = conv1_shapes(B, T, F, &To, &Fo);
+    if (rc != ASR_OK) return rc;
+    if (cin != 3 || (Fo & 1)) return ASR_EUNSUPPORTED;
+    if (!x || !dy || !dw || !workspace || workspace_bytes < asr_conv1c_7x7s2_workspace_bytes(cin))
+        return ASR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int ROWS = 8;
+    Conv1Params p;
+    p.x = x; p.wpack = nullptr; p.y = (__bf16 *)const_cast<void *>(dy);
+    p.partial = (float *)((char *)workspace + 3 * 4 * 64 * 8 * 2);
+    p.B = B; p.T = T; p.F = F; p.To = To; p.Fo = Fo;
+    const int FP = (2 * (Fo - 1) + 8 + 3) & ~3;
+    size_t lds = (size_t)3 * (ROWS + 8) * Fo * 16 + (size_t)ROWS * Fo * PIX + (size_t)3 * (ROWS + 8) * FP * 2;
+    if (lds < 4 * 1024 * 4) lds = 4 * 1024 * 4;                    // the final four-wave sums
+    if (lds > 64 * 1024) return ASR_EUNSUPPORTED;
+    const int chunks = B * ((To + ROWS - 1) / ROWS);
+    const int nwg = chunks < C1_WGS ? chunks : C1_WGS;
+    const int di = (ROWS * Fo * 4 + 255) / 256, rpt = ((ROWS + 8) * F * 3 + 255) / 256;
+    if (di > 8 || rpt > 24) return ASR_EUNSUPPORTED;
+    void (*kern)(Conv1Params) = di <= 5 && rpt <= 16 ? conv1c_wgrad_kernel<3, ROWS, 5, 16>
+                                                      : conv1c_wgrad_kernel<3, ROWS, 8, 24>;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(conv1c_wgrad_reduce_kernel<3>, dim3(2 * 3 * 1024 / 64), dim3(1024), 0, s, p.partial, nwg, dw);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }

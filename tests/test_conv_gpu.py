@@ -109,6 +109,52 @@ def test_first_convolution_forward_and_weight_gradient(B, T, F):
     assert float((dw.cpu() - want_dw).abs().max()) <= 2e-3 * float(want_dw.abs().max())
 
 
+# (the WSJ recipes' features: 81 mel bins x 3 channels -> Fo = 38; 49 x 3 -> Fo = 22; more chunks
+#  than persistent workgroups; a last chunk of fewer than 8 rows)
+@pytest.mark.parametrize('B,T,F', [(2, 50, 81), (1, 333, 81), (3, 7, 49), (300, 31, 81), (5, 1000, 81)])
+def test_first_convolution_three_input_channels(B, T, F):
+    """Conv2d(3, 32, 7x7, stride (1, 2), padding (6, 0)) on [B, T, F, 3] features — the layout
+    the reference's batches have before deep_speech_2.py:127 permutes them"""
+    from att_speech import _native
+    g = torch.Generator().manual_seed(B * 31 + T + F)
+    x = torch.randn(B, T, F, 3, generator=g)
+    w = torch.randn(32, 3, 7, 7, generator=g) * 0.1
+    dev = torch.device('cuda:0')
+    assert _native.conv1_supported(F, 3)
+    y, sums = _native.conv1_fwd(x.to(dev), w.to(dev), want_sums=True)
+    yd = y.double()
+    np.testing.assert_allclose(sums[0].cpu().numpy(), yd.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(sums[1].cpu().numpy(), (yd * yd).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5)
+    xr = x.to(torch.bfloat16).float().permute(0, 3, 1, 2)           # operands as the kernel rounds them
+    want = F_conv(xr, w.to(torch.bfloat16).float())
+    got = y.float().cpu()
+    assert tuple(got.shape) == tuple(want.shape)
+    assert float((got - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    dy = torch.randn(want.shape, generator=g)
+    dyb = dy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dw = _native.conv1_wgrad(x.to(dev), dyb)
+    torch.cuda.synchronize()
+    want_dw = torch.nn.grad.conv2d_weight(xr, (32, 3, 7, 7), dyb.float().cpu(), stride=(1, 2),
+                                          padding=(6, 0))
+    assert float((dw.cpu() - want_dw).abs().max()) <= 2e-3 * float(want_dw.abs().max())
+
+
+def test_first_convolution_three_channels_module_path():
+    """native_conv.conv1 takes the reference's permuted [B, 3, T, F] view without a copy"""
+    from att_speech.modules.encoders import native_conv
+    dev = torch.device('cuda:0')
+    conv = torch.nn.Conv2d(3, 32, (7, 7), stride=(1, 2), padding=(6, 0)).to(dev)
+    feats = torch.randn(2, 60, 81, 3, device=dev)
+    x = feats.permute(0, 3, 1, 2)
+    assert native_conv.first_supported(conv, x)
+    y, sums = native_conv.conv1(x, conv)
+    want = F.conv2d(x.to(torch.bfloat16).float(), conv.weight.detach().to(torch.bfloat16).float(), None, (1, 2), (6, 0))
+    assert float((y.float() - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    y.float().square().sum().backward()
+    assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all()
+    assert not native_conv.first_supported(conv, torch.randn(2, 3, 60, 80, device=dev))     # odd Fo
+
+
 def F_conv(x, w):
     return F.conv2d(x, w, None, (1, 2), (6, 0))
 
