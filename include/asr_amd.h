@@ -93,9 +93,10 @@ int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
  * transcendental, no LDS and no barrier on the recurrence), alpha / beta are block floating
  * point (one binary exponent per lane, rescaled by exact powers of two), every posterior row
  * is normalised by its own total; only every second alpha / beta row goes through the
- * workspace (the consumer recomputes the one in between).  The word behind the last
- * utterance's workspace region (offset B * (T + 2) * (roundup(N, 64) + 64) floats) counts the
- * utterances of the launch that were redone by the log-domain body.
+ * workspace (the consumer recomputes the one in between).
+ *   redo_count  device word of the caller or NULL: incremented once per utterance that the
+ *               log-domain body had to redo; never reset by the library (a running counter:
+ *               the caller takes differences).  (ABI v17)
  * asr_lattice_fwbw_band_supported says whether the SHAPES qualify; the graph of every
  * utterance is checked inside the kernel, and an utterance whose graph has another shape,
  * has no feasible alignment, or whose numbers leave the fp32 range runs the generic
@@ -114,7 +115,7 @@ int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
                               float *out_logZ, float *out_grad,
                               float *out_logZ_bwd,
                               void *workspace, int64_t workspace_bytes,
-                              void *stream);
+                              uint32_t *redo_count, void *stream);
 
 /*
  * Alpha-only scan: path_reduction's autodiff branch evaluated forward

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -37,7 +37,7 @@ _SIGNATURES = {
     'asr_lattice_fwbw_band_supported': (_i, [_i] * 7),
     'asr_lattice_fwbw_band_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp,
-                                       _vp, _i64, _vp]),
+                                       _vp, _i64, _vp, _vp]),
     'asr_lattice_viterbi_workspace_bytes': (_i64, [_i, _i, _i]),
     'asr_lattice_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _f, _i, _vp, _vp, _vp, _i64,
@@ -229,16 +229,28 @@ def _host_band_check(gm):
 # below both).  The kernel counts them; the count of one call is read (without a sync: pinned
 # copy + event) before a later call, and when more than a tenth of a batch was redone the next
 # `_BAND_COOLDOWN` calls go to the log-domain kernel, which does not care.
-_BAND_STATE = {'cool': 0, 'pending': None}
+_BAND_STATE = {'cool': 0, 'pending': None, 'launched': 0, 'seen': (0, 0)}
 _BAND_COOLDOWN = 64
 _BAND_MAX_BATCH = 1 << 30      # no cap: measured faster from 384 utterances up, level with the log-domain kernel below
+_BAND_COUNTER = {}             # device -> (running device counter int32[1], pinned host copy)
+
+
+def _band_counter(device):
+    c = _BAND_COUNTER.get(device)
+    if c is None:
+        c = (torch.zeros(1, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32).pin_memory())
+        _BAND_COUNTER[device] = c
+        _BAND_STATE.update(pending=None, launched=0, seen=(0, 0))
+    return c
 
 
 def _band_policy_allows():
     st = _BAND_STATE
     pend = st['pending']
     if pend is not None and pend[1].query():
-        redone, batch = int(pend[0].item()), pend[2]
+        redone_total, launched_total = int(pend[0].item()), pend[2]
+        redone, batch = redone_total - st['seen'][0], launched_total - st['seen'][1]
+        st['seen'] = (redone_total, launched_total)
         st['pending'] = None
         if redone * 10 > batch:
             st['cool'] = _BAND_COOLDOWN
@@ -248,16 +260,17 @@ def _band_policy_allows():
     return True
 
 
-def _band_policy_record(ws, B, T, N):
-    if _BAND_STATE['pending'] is not None:
+def _band_policy_record(device, B):
+    """the kernel's running redo counter, read without a sync (pinned copy + event) once in a while"""
+    st = _BAND_STATE
+    st['launched'] += B
+    if st['pending'] is not None:
         return
-    wc = (N + 63) // 64 * 64 + 64
-    off = B * (T + 2) * wc * 4
-    host = torch.empty(1, dtype=torch.int32).pin_memory()
-    host.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
+    dev_cnt, host = _band_counter(device)
+    host.copy_(dev_cnt, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    _BAND_STATE['pending'] = (host, ev, B)
+    st['pending'] = (host, ev, st['launched'])
 
 
 def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
@@ -284,29 +297,28 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()
     # band lattices (CTC chains of mono-character transcripts): the linear-domain kernel
-    # (ASR_LATTICE_BAND=0: the log-domain state-labelled kernel, for A/B runs)
-    # ASR_LATTICE_BAND: 0 never, 2 always, 1 (default) by batch size and redo rate.  The band
-    # kernel keeps 2 chain + 2 helper waves per utterance (the log-domain kernel 8): up to two
-    # utterances per CU it is 25-30 % faster (B=512: 97 vs 123 us), with three per CU its two
-    # busy waves per utterance leave the SIMDs under-occupied in the first half and the 8-wave
-    # kernel is 7 % ahead (B=768: 150 vs 140 us)
+    # (csrc/lattice_band.inc).  ASR_LATTICE_BAND: 0 never (the log-domain
+    # state-labelled kernel, for A/B runs), 2 always, 1 (default) unless most of a recent batch
+    # had to be redone in the log domain
     band_env = os.environ.get('ASR_LATTICE_BAND', '1')
     use_band = (graph.band and band_env != '0' and
                 L.asr_lattice_fwbw_band_supported(T, B, C, graph.N, graph.Kin, graph.Kout, graph.Bg))
     if use_band and band_env != '2' and (B > _BAND_MAX_BATCH or not _band_policy_allows()):
         use_band = False
-    entry = L.asr_lattice_fwbw_band_f32 if use_band else L.asr_lattice_fwbw_f32
-    check(entry(
-        _p(lp), T, B, C, _p(lens), _p(graph.src_in), _p(graph.il_in),
-        _p(graph.w_in), _p(graph.term), _p(graph.dst_out), _p(graph.il_out),
-        _p(graph.w_out), graph.N, graph.Kin, graph.Kout, graph.Bg,
-        float(neg_inf), _p(logZ), _p(grad), _p(zb), _p(ws), nbytes, _stream()),
-        'asr_lattice_fwbw_band_f32' if use_band else 'asr_lattice_fwbw_f32')
+    args = (_p(lp), T, B, C, _p(lens), _p(graph.src_in), _p(graph.il_in),
+            _p(graph.w_in), _p(graph.term), _p(graph.dst_out), _p(graph.il_out),
+            _p(graph.w_out), graph.N, graph.Kin, graph.Kout, graph.Bg,
+            float(neg_inf), _p(logZ), _p(grad), _p(zb), _p(ws), nbytes)
+    if use_band:
+        check(L.asr_lattice_fwbw_band_f32(*args, _p(_band_counter(lp.device)[0]), _stream()),
+              'asr_lattice_fwbw_band_f32')
+    else:
+        check(L.asr_lattice_fwbw_f32(*args, _stream()), 'asr_lattice_fwbw_f32')
     if hook is not None:
         ev1.record()
         hook.append((ev0, ev1))
     if use_band and band_env != '2':
-        _band_policy_record(ws, B, T, graph.N)
+        _band_policy_record(lp.device, B)
     if use_band and os.environ.get('ASR_LATTICE_BAND_DEBUG'):
         # development aid: why utterances were redone by the in-kernel log-domain body (the last
         # word of each utterance's workspace region, csrc/lattice_band.inc); synchronises

@@ -29,6 +29,7 @@ struct FwbwParams {
     float neg_inf;
     float *logZ, *grad, *logZ_bwd;
     float *alphas;  // workspace, [T+2,B,roundup(N,64)] for the meet-in-the-middle kernels
+    unsigned *redo; // band kernel: running count of utterances redone by the fallback body, or null
 };
 
 // KR > 0: every thread owns ONE state (N <= blockDim) and keeps its <= KR
@@ -1213,6 +1214,7 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     p.N = N; p.Kin = Kin; p.Kout = Kout; p.Bg = Bg; p.neg_inf = neg_inf;
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
+    p.redo = nullptr;
 
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
@@ -1328,7 +1330,7 @@ extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
                                          int N, int Kin, int Kout, int Bg, float neg_inf,
                                          float *out_logZ, float *out_grad,
                                          float *out_logZ_bwd,
-                                         void *workspace, int64_t workspace_bytes,
+                                         void *workspace, int64_t workspace_bytes, uint32_t *redo_count,
                                          void *stream) {
     if (T < 0 || B < 0 || C <= 0 || N <= 0 || Kin <= 0 || Kout <= 0) return ASR_EINVAL;
     if (Bg != 1 && Bg != B) return ASR_EINVAL;
@@ -1347,16 +1349,16 @@ extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
     p.N = N; p.Kin = Kin; p.Kout = Kout; p.Bg = Bg; p.neg_inf = neg_inf;
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
+    p.redo = nullptr;
     // the in-kernel fallback (lattice_fwbw_generic_body<0>) needs 2 Npad + 2 Cpad + 64 words
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)band::LDS_WORDS * sizeof(float);
     const size_t lds_gen = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
     if (lds_gen > lds) lds = lds_gen;
     const int grid = 8 * ((B + 7) / 8);       // blocks b, b + 8, ... (one XCD) take neighbouring utterances
-    // the count of utterances redone by the fallback body: first word of the workspace's tail pad
-    if (hipMemsetAsync((float *)workspace + (size_t)B * (size_t)(T + 2) * (round_up(N, 64) + 64), 0, 4,
-                       (hipStream_t)stream) != hipSuccess)
-        return ASR_ELAUNCH;
+    // the count of utterances redone by the fallback body: a RUNNING counter of the caller's
+    // (never reset here: a memset in front of every launch cost more than 5 % of the launch)
+    p.redo = redo_count;
     hipLaunchKernelGGL(lattice_fwbw_band_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }

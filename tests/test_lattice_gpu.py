@@ -555,9 +555,20 @@ def test_band_kernel_falls_back_inside_the_launch(oracle_lib):
     lp = torch.log_softmax(torch.from_numpy(rng.standard_normal((T, B, C)).astype(np.float32)), -1).numpy()
     lens = np.array([40, 36, 30], np.int32)
     want = oracle_lib.path_logsumexp(lp, lens, mats)
+    from att_speech import _native
+    cnt = _native._band_counter(dev())[0]
+    before = int(cnt.item())
     logZ, grad, zb = run_fwbw(lp, lens, mats, want_bwd=True, band=True)
     np.testing.assert_allclose(logZ, want['logZ'], rtol=RTOL_LOSS)
     assert_posteriors(grad, want['grad'], lp, lens, mats, oracle_lib)
+    # ... and counted in the caller's running counter (all three utterances: wrong graph shape),
+    # which the host policy reads without a sync and answers with a cool-down on the log-domain
+    # kernel once more than a tenth of a batch was redone
+    assert int(cnt.item()) - before == B
+    st = _native._BAND_STATE
+    torch.cuda.synchronize()
+    assert st['pending'] is not None and not _native._band_policy_allows() and st['cool'] == _native._BAND_COOLDOWN - 1
+    st.update(cool=0)
 
 
 def test_full_size_bichar_numerator_properties():
