@@ -305,7 +305,7 @@ def tcn_decode_rate(dev, B=64, T=1000, beam=10, steps=120):
             'workload': 'lattice_decoding/tcn.yaml dimensions, random weights, fixed label-step budget'}
 
 
-def time_extra_workload(workload, B, T, steps, warmup, dev, rank, world, hooks_on=True):
+def time_extra_workload(workload, B, T, steps, warmup, dev, rank, world, hooks_on=True, fused_on=True):
     """A few timed training steps of another BASELINE config (same step definition, same
     hooks, same barrier / max-over-ranks timing as the headline) -> dict for `extra_workloads`."""
     from att_speech.dp import FlatGradBucket, broadcast_parameters, train_step
@@ -329,12 +329,16 @@ def time_extra_workload(workload, B, T, steps, warmup, dev, rank, world, hooks_o
                  PolyakDecay(decay_rates=[0.9998])]
         for h in hooks:
             h.pre_run(model, opt)
+    fused = None
+    if fused_on and hooks_on:
+        from att_speech.fused_step import FusedClipAdam
+        fused = FusedClipAdam.from_optimizer(opt, bucket, hooks[0])
     skipped = []
 
     def step(record):
         with contextlib.redirect_stdout(sys.stderr):
             out, skip = train_step(model, opt, ((feats_d, lens, None, texts, llens), {}),
-                                   hooks=hooks, bucket=bucket)
+                                   hooks=hooks, bucket=bucket, fused=fused)
         if record:
             skipped.append(bool(skip))
         return out['loss']
@@ -351,6 +355,8 @@ def time_extra_workload(workload, B, T, steps, warmup, dev, rank, world, hooks_o
     for _ in range(steps):
         loss = step(True)
     fence()
+    if fused is not None:        # the device's decisions of the timed steps
+        skipped = [a or rec[2] for a, rec in zip(skipped, fused.drain()[-steps:])]
     t = torch.tensor([time.time() - t0], dtype=torch.float64, device=dev)
     frames = torch.tensor([float(lens.sum())], dtype=torch.float64, device=dev)
     if world > 1:
@@ -466,6 +472,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hooks', action='store_true',
                     help='leave out GradientClipping / PolyakDecay (recipe hooks)')
+    ap.add_argument('--host-step', action='store_true',
+                    help='clip / skip decision and Adam on the host side (GradientClipping hook + '
+                         'torch.optim.Adam, one read-back per step) instead of att_speech.fused_step')
     ap.add_argument('--no-extra', action='store_true',
                     help='leave out the bi-char numerator roofline launch and the decode rate')
     ap.add_argument('--dry-run-launcher', action='store_true', help=argparse.SUPPRESS)
@@ -534,6 +543,12 @@ def main():
                  PolyakDecay(decay_rates=[0.9998])]
         for h in hooks:
             h.pre_run(model, opt)
+    # the step boundary on the device (att_speech/fused_step.py): same clip / skip rule and Adam
+    # arithmetic as the hook + torch.optim.Adam, no read-back between backward and the update
+    fused = None
+    if hooks and not a.host_step:
+        from att_speech.fused_step import FusedClipAdam
+        fused = FusedClipAdam.from_optimizer(opt, bucket, hooks[0])
 
     class _Recorder(object):                 # times the lattice call of the recorded steps
         def __init__(self):
@@ -552,7 +567,7 @@ def main():
         fwd.on = record
         with contextlib.redirect_stdout(sys.stderr):     # hooks print like the reference; stdout is the JSON line
             out, skip = train_step(model, opt, ((feats_d, lens, None, texts, llens), {}),
-                                   hooks=hooks, bucket=bucket, forward=fwd)
+                                   hooks=hooks, bucket=bucket, forward=fwd, fused=fused)
         if record:
             skipped.append(bool(skip))
         return out['loss']
@@ -582,6 +597,9 @@ def main():
         loss = step(record=True)
     fence()
     dt = time.time() - t0
+    if fused is not None:        # the device's decisions of the timed steps, read after the fence
+        skipped = [s_ or rec[2] for s_, rec in zip(skipped, fused.drain()[-a.steps:])]
+        assert fused.steps_taken == a.warmup + a.steps - sum(fused_rec[2] for fused_rec in fused.history)
     # every timed step must have taken its optimizer step (work skipped inside the
     # timed region would invalidate the number)
     assert not any(skipped), 'optimizer step skipped in %d of %d timed steps' % (sum(skipped), len(skipped))
@@ -605,7 +623,8 @@ def main():
         torch.cuda.empty_cache()
         for wl, wb in ([('ctc_bi', 512), ('ctcg_bi_cde', 256)] if world == 1 else [('ctc_bi', 512)]):
             progress('extra workload %s' % wl)
-            extra.append(time_extra_workload(wl, wb, T, 5, 2, dev, rank, world, not a.no_hooks))
+            extra.append(time_extra_workload(wl, wb, T, 5, 2, dev, rank, world, not a.no_hooks,
+                                             not a.host_step))
     else:
         final_state = model.state_dict() if rank == 0 else None
 
@@ -635,6 +654,8 @@ def main():
                        'batch_per_gpu': B, 'global_batch': B * world, 'frames': T,
                        'classes': C, 'parallelism': 'dp%d' % world,
                        'optimizer_steps': len(skipped) - sum(skipped),
+                       'step_boundary': ('device: att_speech.fused_step (clip / skip decision + Adam, no read-back)'
+                                         if fused is not None else 'host: hook + torch.optim.Adam, one read-back'),
                        'first_loss': loss0, 'final_loss': float(loss.detach())},
             'roofline': {'bound': 'hbm', 'kernel': 'lattice_fwbw (alpha/beta scan): %s' % (
                              mono_lattice_kernel(B) if order == 1 else 'lattice_fwbw_sl_kernel<3, 8, 0>'),

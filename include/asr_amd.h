@@ -502,6 +502,38 @@ int asr_beam_step_f32(const float *logits, const float *scores_in, float *scores
                       int32_t *best_len, int32_t *best_tokens, int32_t *new_input,
                       int32_t *parent, int32_t *done_and_scratch, void *stream);
 
+/*
+ * The step boundary on the device (ABI v18): the reference's GradientClipping hook
+ * (att_speech/modules/hooks/gradient_clipping.py:13-53: clip_grad_norm_ to clip_norm, skip the
+ * optimizer step when the unclipped norm exceeds skip_step_norm) and torch.optim.Adam.step
+ * (trainer.py:262-266; amsgrad / maximize off, weight_decay as L2) without a host read-back
+ * between backward and the update.
+ *
+ * asr_grad_sumsq_partials_f32: partials[i] = sum of g^2 over the i-th of nparts equal slices of
+ * the flat gradient g [n] (nparts <= 65535).
+ * asr_adam_clip_step_f32: norm = sqrt(sum partials); the step is skipped when norm >
+ * skip_norm, when it is not finite, or when *err_word != 0 (the persistent LSTM's error word,
+ * may be NULL); otherwise g is scaled by min(1, clip_norm / (norm + 1e-6)) and Adam step number
+ * *step_in + 1 updates m_flat / v_flat [n] and the parameters.  The parameters stay where the
+ * caller's framework allocated them: `chunks` (device memory, nchunks entries, one workgroup each)
+ * lists pieces of at most asr_adam_chunk_elems() elements: `param` = address of the piece
+ * inside its parameter tensor, `flat_offset` = its offset in g / m / v.  *step_out = *step_in + 1
+ * (or *step_in when skipped); step_in != step_out (the caller alternates two words).
+ * stats [4] = {norm, clipped, skipped, err} as floats, for the host to read when it likes.
+ */
+typedef struct AsrAdamChunk {
+    void *param;
+    uint32_t flat_offset;
+    uint32_t count;
+} AsrAdamChunk;
+int asr_adam_chunk_elems(void);
+int asr_grad_sumsq_partials_f32(const float *g, int64_t n, float *partials, int nparts, void *stream);
+int asr_adam_clip_step_f32(const AsrAdamChunk *chunks, int nchunks, const float *g_flat,
+                           float *m_flat, float *v_flat, const float *partials, int nparts,
+                           const uint32_t *err_word, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, float clip_norm, float skip_norm,
+                           const int32_t *step_in, int32_t *step_out, float *stats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -59,6 +59,10 @@ _SIGNATURES = {
     'asr_log_softmax_shift_fwd_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'asr_log_softmax_shift_bwd_f32': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     'asr_sum_leading_f32': (_i, [_vp, _i, _i64, _vp, _vp]),
+    'asr_adam_chunk_elems': (_i, []),
+    'asr_grad_sumsq_partials_f32': (_i, [_vp, _i64, _vp, _i, _vp]),
+    'asr_adam_clip_step_f32': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _f, _f,
+                                    _vp, _vp, _vp, _vp]),
     'asr_split_bf16_f32': (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     'asr_log_softmax_shift_bwd_split_blocks': (_i, [_i64]),
     'asr_log_softmax_shift_bwd_split_bf16': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp]),

@@ -113,14 +113,21 @@ def broadcast_parameters(module, src=0, group=None):
 
 
 def train_step(model, optimizer, batch_args, hooks=(), bucket=None, current_iteration=0,
-               group=None, forward=None):
+               group=None, forward=None, fused=None):
     """One training step in the reference's order (trainer.py:229-272):
     pre_train_forward hooks -> forward -> pre_backward hooks -> zero grads ->
     backward -> [gradient all-reduce over `bucket`] -> post_backward hooks (they
     see the GLOBAL gradient, e.g. GradientClipping) -> optimizer.step() unless a
     hook asked to skip -> post_optimizer_step hooks.  `batch_args` are the
     arguments of `model.forward` (or of `forward` if given).  Returns
-    (loss_dict, skipped)."""
+    (loss_dict, skipped).
+
+    `fused` (an `att_speech.fused_step.FusedClipAdam` over `bucket`): the GradientClipping
+    hook's clip / skip decision and the Adam update are taken on the device, with no read-back
+    in the step; `skipped` then only reports what the other hooks asked for, the device's
+    decisions arrive later through `fused.poll()` / `fused.drain()`, and a timed-out LSTM
+    hand-off (whose step the device has skipped on every rank) is raised when its statistics
+    arrive, a few steps late."""
     for h in hooks:
         h.pre_train_forward(model=model, optimizer=optimizer,
                             current_iteration=current_iteration)
@@ -149,6 +156,23 @@ def train_step(model, optimizer, batch_args, hooks=(), bucket=None, current_iter
             # a timed-out hand-off poisons ONE rank's gradient with NaN, and the all-reduce has
             # just spread it: every rank must learn of it and discard the step together
             dist.all_reduce(err_word, op=dist.ReduceOp.MAX, group=group)
+    if fused is not None:
+        from att_speech import _native
+        from att_speech.modules.hooks.gradient_clipping import GradientClipping
+        assert bucket is not None and fused.bucket is bucket
+        for h in hooks:        # every hook but the clipping one, which the device step stands for
+            if not isinstance(h, GradientClipping):
+                skip = skip or bool(h.post_backward(model=model, optimizer=optimizer,
+                                                    current_iteration=current_iteration, loss=loss))
+        if not skip:
+            fused.step(err_word)
+        for h in hooks:
+            h.post_optimizer_step(model=model, optimizer=optimizer,
+                                  current_iteration=current_iteration, loss=loss)
+        for rec in fused.poll():
+            if rec[3]:
+                _native.lstm_raise_error(err_word)
+        return loss_dict, skip
     if err_word is not None:
         # ONE read-back per step: the gradient norm the clipping hook wants and the error word
         if bucket is not None:
