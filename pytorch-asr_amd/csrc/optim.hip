@@ -44,7 +44,7 @@ struct AdamParams {
     const float *g;
     float *m, *v;
     const float *partials;
-    int nparts;
+    int nparts, nchunks;
     const uint32_t *err;
     float lr, beta1, beta2, eps, wd, clip, skip;
     const int32_t *step_in;
@@ -83,20 +83,23 @@ __global__ __launch_bounds__(TPB) void adam_clip_step_kernel(AdamParams p) {
     __syncthreads();
     if (sh[1] != 0.f) return;
     const float coef = sh[0], step_size = sh[2], bc2s = sh[3];
-    const AsrAdamChunk c = p.chunks[blockIdx.x];
-    float *const w = (float *)c.param;
     const float b1 = p.beta1, b2 = p.beta2;
-    for (uint32_t i = threadIdx.x; i < c.count; i += TPB) {
-        const size_t f = (size_t)c.flat_offset + i;
-        float g = p.g[f] * coef;
-        float x = w[i];
-        if (p.wd != 0.f) g = fmaf(p.wd, x, g);
-        const float m = b1 * p.m[f] + (1.f - b1) * g;           // exp_avg.lerp_(grad, 1 - beta1)
-        const float v = b2 * p.v[f] + (1.f - b2) * g * g;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-        p.m[f] = m;
-        p.v[f] = v;
-        const float denom = sqrtf(v) / bc2s + p.eps;
-        w[i] = x - step_size * (m / denom);
+    // (a block walks several chunks: the norm / bias-correction prologue above is paid once)
+    for (int ci = blockIdx.x; ci < p.nchunks; ci += gridDim.x) {
+        const AsrAdamChunk c = p.chunks[ci];
+        float *const w = (float *)c.param;
+        for (uint32_t i = threadIdx.x; i < c.count; i += TPB) {
+            const size_t f = (size_t)c.flat_offset + i;
+            float g = p.g[f] * coef;
+            float x = w[i];
+            if (p.wd != 0.f) g = fmaf(p.wd, x, g);
+            const float m = b1 * p.m[f] + (1.f - b1) * g;           // exp_avg.lerp_(grad, 1 - beta1)
+            const float v = b2 * p.v[f] + (1.f - b2) * g * g;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+            p.m[f] = m;
+            p.v[f] = v;
+            const float denom = sqrtf(v) / bc2s + p.eps;
+            w[i] = x - step_size * (m / denom);
+        }
     }
 }
 
@@ -123,10 +126,11 @@ extern "C" int asr_adam_clip_step_f32(const AsrAdamChunk *chunks, int nchunks, c
         return ASR_EINVAL;
     AdamParams p;
     p.chunks = chunks; p.g = g_flat; p.m = m_flat; p.v = v_flat;
-    p.partials = partials; p.nparts = nparts; p.err = err_word;
+    p.partials = partials; p.nparts = nparts; p.nchunks = nchunks; p.err = err_word;
     p.lr = lr; p.beta1 = beta1; p.beta2 = beta2; p.eps = eps; p.wd = weight_decay;
     p.clip = clip_norm; p.skip = skip_norm;
     p.step_in = step_in; p.step_out = step_out; p.stats = stats;
-    hipLaunchKernelGGL(adam_clip_step_kernel, dim3(nchunks), dim3(TPB), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(adam_clip_step_kernel, dim3(nchunks < 2048 ? nchunks : 2048), dim3(TPB), 0,
+                       (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
