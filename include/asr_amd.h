@@ -515,7 +515,7 @@ int asr_beam_step_f32(const float *logits, const float *scores_in, float *scores
  * skip_norm, when it is not finite, or when *err_word != 0 (the persistent LSTM's error word,
  * may be NULL); otherwise g is scaled by min(1, clip_norm / (norm + 1e-6)) and Adam step number
  * *step_in + 1 updates m_flat / v_flat [n] and the parameters.  The parameters stay where the
- * caller's framework allocated them: `chunks` (device memory, nchunks entries, one workgroup each)
+ * caller's framework allocated them: `chunks` (device memory, nchunks entries)
  * lists pieces of at most asr_adam_chunk_elems() elements: `param` = address of the piece
  * inside its parameter tensor, `flat_offset` = its offset in g / m / v.  *step_out = *step_in + 1
  * (or *step_in when skipped); step_in != step_out (the caller alternates two words).
