@@ -475,6 +475,9 @@ def main():
     ap.add_argument('--host-step', action='store_true',
                     help='clip / skip decision and Adam on the host side (GradientClipping hook + '
                          'torch.optim.Adam, one read-back per step) instead of att_speech.fused_step')
+    ap.add_argument('--sync-bn', action='store_true',
+                    help='N > 1: BatchNorm statistics over all replicas (att_speech.dp.enable_sync_batchnorm), '
+                         'as in the single-process reference, instead of per replica')
     ap.add_argument('--no-extra', action='store_true',
                     help='leave out the bi-char numerator roofline launch and the decode rate')
     ap.add_argument('--dry-run-launcher', action='store_true', help=argparse.SUPPRESS)
@@ -514,6 +517,9 @@ def main():
     sb = {'features': feats[:2].clone(), 'features_lengths': lens[:2].clone(), 'spkids': None}
     model = SpeechModel(enc_cfg, dec_cfg, sb, C, [str(i) for i in range(S)]).to(dev)
     broadcast_parameters(model)
+    if a.sync_bn:
+        from att_speech.dp import enable_sync_batchnorm
+        enable_sync_batchnorm(True)
     bucket = FlatGradBucket(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     feats_d = feats.to(dev)                          # inputs resident in HBM
@@ -653,6 +659,7 @@ def main():
                                       hook_txt, FEATS[0], FEATS[1], T),
                        'batch_per_gpu': B, 'global_batch': B * world, 'frames': T,
                        'classes': C, 'parallelism': 'dp%d' % world,
+                       'batch_norm': 'statistics over all replicas' if a.sync_bn else 'per-replica statistics',
                        'optimizer_steps': len(skipped) - sum(skipped),
                        'step_boundary': ('device: att_speech.fused_step (clip / skip decision + Adam, no read-back)'
                                          if fused is not None else 'host: hook + torch.optim.Adam, one read-back'),

@@ -368,6 +368,26 @@ int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_bias, int B,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
+ * The same backward in two halves, for replicas that share their batch statistics (SyncBN-style
+ * data parallelism, att_speech.dp.enable_sync_batchnorm; the single-process reference normalises
+ * over the whole batch, deep_speech_2.py:21,60-73) (ABI v19).  phase 1: the per-channel sums
+ * {sum dy', sum dy' xhat} of THIS replica as 2 C interleaved doubles at the start of the workspace,
+ * and dgamma / dbeta / dconv_bias from them (parameter gradients are local: the gradient
+ * all-reduce adds the replicas up); phase 2: dx from the sums the caller left there — all-reduced
+ * over the replicas — and n_total, the number of elements per channel they stand for.  phase 0 =
+ * asr_bn_act_bwd_f32.
+ */
+int asr_bn_act_bwd_phase_f32(const void *x, int x_bf16, const float *conv_bias, int B, int C, int H, int W,
+                             const float *gamma, const float *beta,
+                             const float *save_mean, const float *save_invstd,
+                             int channels_last,
+                             int training, float lo, float hi,
+                             const void *dy, int dy_bf16, int dy_time_major,
+                             void *dx, float *dgamma, float *dbeta, float *dconv_bias,
+                             void *workspace, int64_t workspace_bytes, int phase, double n_total,
+                             void *stream);
+
+/*
  * log_softmax over all C classes followed by the per-frame max stabilisation of
  * FSTDecoder.get_fst_loss (advanced_decoder.py:444-452 with normalize_by_dim = 0, then
  * :479-484) in ONE pass over x [T, B, C]: y = log_softmax(x) - max_c log_softmax(x) = x - max_c x,

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -91,6 +91,8 @@ _SIGNATURES = {
                                 _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_bn_act_bwd_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
                                 _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'asr_bn_act_bwd_phase_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
+                                      _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, ctypes.c_double, _vp]),
 }
 
 # include/asr_amd_experiments.h: exported only by `make EXPERIMENTS=1` builds; bound when
@@ -768,10 +770,13 @@ def bn_act_fwd(x, gamma, beta, running_mean, running_var, training, momentum, ep
 
 
 def bn_act_bwd(x, gamma, beta, mean, invstd, training, lo, hi, dy, time_major=False,
-               conv_bias=None):
+               conv_bias=None, sync=None):
     """asr_bn_act_bwd_f32 -> (dx [B,C,H,W] f32 in x's memory format, dgamma [C], dbeta [C],
     dconv_bias [C] | None);
-    dy f32 or bf16 in the layout the forward wrote."""
+    dy f32 or bf16 in the layout the forward wrote.
+    sync: a callable (sums [2 C] f64 device tensor, n_local) -> n_total that adds the per-channel
+    sums up over the replicas in place (SyncBN-style data parallelism): the call then runs as
+    asr_bn_act_bwd_phase_f32 phase 1 (local sums + parameter gradients), sync, phase 2 (dx)."""
     x, cl = _nchw_or_nhwc(x, 'x', x.dtype if x.dtype == torch.bfloat16 else torch.float32)
     if cl and (x.shape[1] % 4 or x.shape[1] > 1024 or 256 % (x.shape[1] // 4)):
         x, cl = x.contiguous(), False
@@ -794,6 +799,17 @@ def bn_act_bwd(x, gamma, beta, mean, invstd, training, lo, hi, dy, time_major=Fa
         dcb = torch.empty(C, dtype=torch.float32, device=x.device)
     nbytes = L.asr_bn_act_workspace_bytes(C)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    if sync is not None and training:
+        def phase(k, n_total):
+            check(L.asr_bn_act_bwd_phase_f32(
+                _p(x), int(x.dtype == torch.bfloat16), _p(conv_bias), B, C, H, W, _p(gamma), _p(beta),
+                _p(mean), _p(invstd), int(cl), 1, float(lo), float(hi), _p(dy),
+                int(dy.dtype == torch.bfloat16), int(time_major), _p(dx), _p(dgamma), _p(dbeta), _p(dcb),
+                _p(ws), nbytes, k, float(n_total), _stream()), 'asr_bn_act_bwd_phase_f32')
+        phase(1, 0.0)
+        sums = ws[:2 * C * 8].view(torch.float64)
+        phase(2, sync(sums, float(B) * H * W))
+        return dx, dgamma, dbeta, dcb
     check(L.asr_bn_act_bwd_f32(_p(x), int(x.dtype == torch.bfloat16), _p(conv_bias), B, C, H, W, _p(gamma), _p(beta), _p(mean), _p(invstd),
                                int(cl), int(bool(training)), float(lo), float(hi), _p(dy),
                                int(dy.dtype == torch.bfloat16), int(time_major), _p(dx),

@@ -112,6 +112,15 @@ def broadcast_parameters(module, src=0, group=None):
             dist.broadcast(t.data, src=src, group=group)
 
 
+def enable_sync_batchnorm(on=True, group=None):
+    """Batch statistics of the fused BatchNorm + Hardtanh (csrc/bnact.hip) over ALL replicas, as
+    in the single-process reference (deep_speech_2.py:21,60-73), instead of per replica: two
+    small all-reduces per BatchNorm layer and direction.  Off by default, like
+    DDP without SyncBatchNorm."""
+    from att_speech.modules.encoders import native_bn
+    native_bn.SYNC.update(on=bool(on), group=group)
+
+
 def train_step(model, optimizer, batch_args, hooks=(), bucket=None, current_iteration=0,
                group=None, forward=None, fused=None):
     """One training step in the reference's order (trainer.py:229-272):

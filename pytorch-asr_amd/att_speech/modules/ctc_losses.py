@@ -36,17 +36,23 @@ class _GroupLogSoftmax(torch.autograd.Function):
 def get_normalized_acts(acts, acts_lens, num_symbols, context_order,
                         normalize_by_dim, normalize_logits=True):
     """reference ctc_losses.py:29-43.  normalize_by_dim > 0 normalises over
-    axis normalize_by_dim + 2 of the [T,B,S,...,S] view; only the last axis
-    (contiguous groups of S) is reachable from the shipped configs."""
+    axis normalize_by_dim + 2 of the [T,B,S,...,S] view.  The last axis (contiguous
+    groups of S: what the shipped configs use) goes straight to the group kernel; any
+    other axis (context_order >= 3) is moved to the end, normalised there and moved back."""
     assert context_order == 1 or num_symbols
     del acts_lens  # unused
     if normalize_by_dim:
-        if normalize_by_dim != context_order - 1:
-            raise NotImplementedError(
-                "normalize_by_dim=%d with context_order=%d is a strided "
-                "normalisation no shipped YAML uses" % (normalize_by_dim, context_order))
         assert acts.size(-1) == num_symbols ** context_order
-        return _GroupLogSoftmax.apply(acts, num_symbols)
+        if not 0 < normalize_by_dim < context_order:
+            raise IndexError("normalize_by_dim=%d: the [T,B,S,...] view of context_order %d has "
+                             "no axis %d" % (normalize_by_dim, context_order, normalize_by_dim + 2))
+        if normalize_by_dim == context_order - 1:
+            return _GroupLogSoftmax.apply(acts, num_symbols)
+        size = acts.size()
+        v = acts.view(*(tuple(size[:2]) + (num_symbols,) * context_order))
+        v = v.movedim(normalize_by_dim + 2, -1).contiguous()
+        y = _GroupLogSoftmax.apply(v.view(size[0], size[1], -1), num_symbols)
+        return y.view(v.shape).movedim(-1, normalize_by_dim + 2).contiguous().view(size)
     elif normalize_logits:
         return _GroupLogSoftmax.apply(acts, acts.size(-1))
     return acts

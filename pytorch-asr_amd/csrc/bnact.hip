@@ -718,14 +718,20 @@ extern "C" int asr_bn_act_fwd_f32(const void *x, int x_bf16, const float *conv_b
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
 
-extern "C" int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_bias, int B, int C, int H, int W,
+// phase 0: everything; 1: the per-channel sums (left in the workspace) and the parameter
+// gradients, which are local quantities; 2: dx from the sums the caller left in the workspace
+// (e.g. all-reduced over the replicas) and the element count n_total they stand for.
+extern "C" int asr_bn_act_bwd_phase_f32(const void *x, int x_bf16, const float *conv_bias, int B, int C, int H, int W,
                                   const float *gamma, const float *beta,
                                   const float *save_mean, const float *save_invstd,
                                   int channels_last,
                                   int training, float lo, float hi,
                                   const void *dy, int dy_bf16, int dy_time_major,
                                   void *dx, float *dgamma, float *dbeta, float *dconv_bias,
-                                  void *workspace, int64_t workspace_bytes, void *stream) {
+                                  void *workspace, int64_t workspace_bytes, int phase,
+                                  double n_total, void *stream) {
+    if (phase < 0 || phase > 2 || (phase == 2 && !(n_total >= 1.0))) return ASR_EINVAL;
+    const bool do_reduce = phase != 2, do_apply = phase != 1;
     if (bad_shape(B, C, H, W) || !x || !gamma || !beta || !save_mean || !save_invstd || !dy ||
         !dx || !dgamma || !dbeta)
         return ASR_EINVAL;
@@ -737,8 +743,9 @@ extern "C" int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_b
     BnParams p;
     p.x = (const float *)x; p.B = B; p.C = C; p.HW = HW; p.Wd = W; p.gamma = gamma; p.beta = beta;
     p.mean = save_mean; p.invstd = save_invstd; p.shift = conv_bias; p.lo = lo; p.hi = hi;
-    const double n = (double)B * HW;
-    hipLaunchKernelGGL(zero_doubles_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, 2 * C);
+    const double n = phase == 2 ? n_total : (double)B * HW;
+    if (do_reduce)
+        hipLaunchKernelGGL(zero_doubles_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, 2 * C);
     if (x_bf16 && !channels_last) return ASR_EUNSUPPORTED;
     if (channels_last) {
         if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) return ASR_EUNSUPPORTED;
@@ -753,34 +760,40 @@ extern "C" int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_b
             const size_t lds = (size_t)tmr * cw * 4;
 #define ASR_BN_BWDT(XT, DT)                                                                          \
             do {                                                                                     \
+                if (do_reduce)                                                                       \
                 hipLaunchKernelGGL((bn_act_bwd_nhwc_tm_kernel<XT, DT, 0>), dim3(g2), dim3(256), lds, \
                                    s, q, (const DT *)dy, sums, n, training, (XT *)dx, tmr);          \
+                if (do_apply)                                                                        \
                 hipLaunchKernelGGL((bn_act_bwd_nhwc_tm_kernel<XT, DT, 1>), dim3(g2), dim3(256), lds, \
                                    s, q, (const DT *)dy, sums, n, training, (XT *)dx, tmr);          \
             } while (0)
             if (x_bf16) { if (dy_bf16) ASR_BN_BWDT(__bf16, __bf16); else ASR_BN_BWDT(__bf16, float); }
             else { if (dy_bf16) ASR_BN_BWDT(float, __bf16); else ASR_BN_BWDT(float, float); }
 #undef ASR_BN_BWDT
-            hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
+            if (do_reduce) hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
         }
         if (!dy_time_major && x_bf16 && C % 8 == 0 && 256 % (C / 8) == 0) {       // 16-byte accesses
 #define ASR_BN_BWD8(DT)                                                                            \
             do {                                                                                   \
+                if (do_reduce)                                                                     \
                 hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<__bf16, DT, 0>), dim3(nwg), dim3(256), 0, s, \
                                    q, (const DT *)dy, sums, n, training, (__bf16 *)dx);            \
+                if (do_apply)                                                                      \
                 hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<__bf16, DT, 1>), dim3(nwg), dim3(256), 0, s, \
                                    q, (const DT *)dy, sums, n, training, (__bf16 *)dx);            \
             } while (0)
             if (dy_bf16) ASR_BN_BWD8(__bf16); else ASR_BN_BWD8(float);
 #undef ASR_BN_BWD8
-            hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
+            if (do_reduce) hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
             return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
         }
 #define ASR_BN_BWDN(XT, DT, TMV)                                                                  \
         do {                                                                                      \
+            if (do_reduce)                                                                        \
             hipLaunchKernelGGL((bn_act_bwd_reduce_nhwc_kernel<XT, DT, TMV>), dim3(nwg), dim3(256), \
                                0, s, q, (const DT *)dy, sums);                                    \
+            if (do_apply)                                                                         \
             hipLaunchKernelGGL((bn_act_bwd_apply_nhwc_kernel<XT, DT, TMV>), dim3(nwg), dim3(256),  \
                                0, s, q, (const DT *)dy, sums, n, training, (XT *)dx);             \
         } while (0)
@@ -792,13 +805,15 @@ extern "C" int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_b
             else { if (dy_time_major) ASR_BN_BWDN(float, float, 1); else ASR_BN_BWDN(float, float, 0); }
         }
 #undef ASR_BN_BWDN
-        hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
+        if (do_reduce) hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
         return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
     }
 #define ASR_BN_BWD(DT, LAY)                                                                       \
     do {                                                                                          \
+        if (do_reduce)                                                                            \
         hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<DT, LAY>), grid, dim3(256), 0, s, p,         \
                            (const DT *)dy, sums);                                                 \
+        if (do_apply)                                                                             \
         hipLaunchKernelGGL((bn_act_bwd_apply_kernel<DT, LAY>), grid, dim3(256), 0, s, p,          \
                            (const DT *)dy, sums, n, training, (float *)dx);                       \
     } while (0)
@@ -808,6 +823,19 @@ extern "C" int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_b
         if (dy_time_major) ASR_BN_BWD(float, 1); else ASR_BN_BWD(float, 0);
     }
 #undef ASR_BN_BWD
-    hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
+    if (do_reduce) hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums, C, gamma, save_invstd, training, dgamma, dbeta, dconv_bias);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_bn_act_bwd_f32(const void *x, int x_bf16, const float *conv_bias, int B, int C, int H, int W,
+                                  const float *gamma, const float *beta,
+                                  const float *save_mean, const float *save_invstd,
+                                  int channels_last,
+                                  int training, float lo, float hi,
+                                  const void *dy, int dy_bf16, int dy_time_major,
+                                  void *dx, float *dgamma, float *dbeta, float *dconv_bias,
+                                  void *workspace, int64_t workspace_bytes, void *stream) {
+    return asr_bn_act_bwd_phase_f32(x, x_bf16, conv_bias, B, C, H, W, gamma, beta, save_mean, save_invstd,
+                                    channels_last, training, lo, hi, dy, dy_bf16, dy_time_major, dx, dgamma,
+                                    dbeta, dconv_bias, workspace, workspace_bytes, 0, 0.0, stream);
 }

@@ -82,3 +82,25 @@ def test_decoder_with_raw_loss_fn():
     out = dec(enc, torch.from_numpy(d['lens'][1:]), torch.from_numpy(d['labels'][1:]),
               torch.from_numpy(d['label_lens'][1:]))
     np.testing.assert_allclose(float(out['loss']), float(d['loss_rep_sym'][1:].sum()), rtol=1e-5)
+
+
+@pytest.mark.parametrize('order,dim', [(2, 1), (3, 1), (3, 2)])
+def test_get_normalized_acts_over_any_context_axis(order, dim):
+    """get_normalized_acts(normalize_by_dim = d) = log_softmax over axis d + 2 of the
+    [T, B, S, ..., S] view (reference ctc_losses.py:29-43, restated here with torch on the CPU):
+    values and gradient, for the last axis (the group kernel directly) and a strided one."""
+    from att_speech.modules.ctc_losses import get_normalized_acts
+    S, T, B = 5, 7, 3
+    g = torch.Generator().manual_seed(11)
+    acts = torch.randn(T, B, S ** order, generator=g) * 3
+    w = torch.randn(T, B, S ** order, generator=g)
+    ref_in = acts.clone().requires_grad_(True)
+    ref = torch.nn.functional.log_softmax(ref_in.view(T, B, *(S,) * order), dim + 2).view(T, B, -1)
+    (ref * w).sum().backward()
+    x = acts.to(dev()).requires_grad_(True)
+    y = get_normalized_acts(x, None, S, order, dim)
+    (y * w.to(dev())).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref_in.grad.numpy(), rtol=1e-4, atol=1e-5)
+    with pytest.raises(IndexError):
+        get_normalized_acts(x, None, S, order, order)
