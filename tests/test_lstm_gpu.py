@@ -18,6 +18,69 @@ def _ref(x, lens, rnn, dy):
     return y.detach(), x.grad, [p.grad.clone() for p in rnn.parameters()]
 
 
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _emulate_bf16_operands(x, lens, rnn):
+    """The arithmetic the kernels are built to do, spelled out with torch on the CPU: the
+    operands of every matrix product (x, W_ih, h_{t-1}, W_hh) rounded to bf16, the products
+    accumulated in fp32, gates / cell / output in fp32.  What separates the kernel from this
+    is the order of the fp32 sums and a few ulp in exp / rcp — and, through the bf16 rounding
+    of h, an occasional flipped last bit of an operand."""
+    T, B, _ = x.shape
+    H = rnn.hidden_size
+    out = torch.zeros(T, B, 2, H)
+    xb = _bf(x)
+    for d, sfx in enumerate(('', '_reverse')):
+        wih = _bf(getattr(rnn, 'weight_ih_l0' + sfx).detach())
+        whh = _bf(getattr(rnn, 'weight_hh_l0' + sfx).detach())
+        for b in range(B):
+            L = int(lens[b])
+            h = torch.zeros(H)
+            c = torch.zeros(H)
+            for t in (range(L) if d == 0 else range(L - 1, -1, -1)):
+                g = wih @ xb[t, b] + whh @ _bf(h)
+                i, f, gg, o = g[:H].sigmoid(), g[H:2 * H].sigmoid(), g[2 * H:3 * H].tanh(), g[3 * H:].sigmoid()
+                c = f * c + i * gg
+                h = o * c.tanh()
+                out[t, b, d] = h
+    return out.view(T, B, 2 * H)
+
+
+@pytest.mark.parametrize('T,B,F,H', [(37, 5, 48, 64), (40, 24, 352, 320), (25, 33, 320, 320)])
+def test_bilstm_is_the_bf16_operand_evaluation(T, B, F, H, monkeypatch):
+    """Whose error is the 3e-2 of the comparison with fp32 below?  The rounding of the
+    operands to bf16, not the kernels: against the bf16-operand evaluation above the outputs
+    agree to 2e-3 of their range (15 times closer than to the fp32 model), and that
+    evaluation itself sits as far from fp32 as the kernels do."""
+    from att_speech.modules.encoders.native_lstm import bilstm
+    monkeypatch.setenv('ASR_GX_FP32', '1')          # (paths that run x.W_ih as a GEMM keep it in fp32)
+    torch.manual_seed(T * 77 + B)
+    lens = sorted(np.random.RandomState(B + 1).randint(1, T + 1, size=B).tolist(), reverse=True)
+    lens[0] = T
+    lens_t = torch.tensor(lens)
+    rnn = nn.LSTM(F, H, bidirectional=True, bias=False)
+    x = torch.randn(T, B, F)
+    with torch.no_grad():
+        emu = _emulate_bf16_operands(x, lens_t, rnn)
+        packed = nn.utils.rnn.pack_padded_sequence(x, lens_t)
+        y32, _ = nn.utils.rnn.pad_packed_sequence(rnn(packed)[0], total_length=T)
+    dev = torch.device('cuda:0')
+    rnn_g = nn.LSTM(F, H, bidirectional=True, bias=False)
+    rnn_g.load_state_dict(rnn.state_dict())
+    rnn_g.to(dev)
+    with torch.no_grad():
+        y = bilstm(x.to(dev), lens_t, rnn_g).view(T, B, 2 * H).cpu()
+    scale = float(y32.abs().max())
+    to_emu = float((y - emu).abs().max())
+    emu_to_32 = float((emu - y32).abs().max())
+    gpu_to_32 = float((y - y32).abs().max())
+    assert to_emu <= 2e-3 * scale, (to_emu, scale)
+    assert float((y - emu).abs().mean()) <= 5e-5 * scale
+    assert gpu_to_32 <= 1.5 * emu_to_32 + 2e-3 * scale, (gpu_to_32, emu_to_32)
+
+
 @pytest.mark.parametrize('T,B,F,H,lens', [
     (37, 5, 48, 64, [37, 30, 30, 11, 1]),
     (60, 40, 352, 320, None),          # first encoder layer shape, 2 batch tiles
