@@ -102,3 +102,84 @@ def test_two_replicas_with_shared_statistics_equal_one_process(with_sums, time_m
     # and it matters: without the switch a replica's output differs from the whole-batch one
     solo = _run(x[i1], dy[i1], with_sums, time_major)
     assert np.abs(solo['y'] - want['y'][4:]).max() > 1e-2
+
+
+def _dp_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, 'pytorch-asr_amd')]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    out = _dp_run(world, rank)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dp_run(world, rank):
+    """three training steps of a SpeechModel on 8 equally long utterances: the whole batch in one
+    process, or this rank's shard of it (device-side step boundary, shared BN statistics)"""
+    import bench
+    from att_speech.dp import (FlatGradBucket, broadcast_parameters, enable_sync_batchnorm,
+                               shard_batch, take_shard, train_step)
+    from att_speech.fused_step import FusedClipAdam
+    from att_speech.models import SpeechModel
+    from att_speech.modules.hooks import GradientClipping
+    dev = torch.device('cuda:0')
+    B, T = 8, 360
+    g = torch.Generator().manual_seed(21)
+    feats = torch.randn(B, T, 40, 1, generator=g)
+    lens = torch.full((B,), T, dtype=torch.int64)
+    llens = torch.randint(5, 30, (B,), generator=g)
+    texts = torch.randint(2, 49, (B, 30), generator=g)
+    enc_cfg, dec_cfg = bench.model_config(1)
+    torch.manual_seed(9)
+    sb = {'features': feats[:2].clone(), 'features_lengths': lens[:2].clone(), 'spkids': None}
+    model = SpeechModel(enc_cfg, dec_cfg, sb, 49, [str(i) for i in range(49)]).to(dev)
+    p0 = [p.detach().float().cpu().numpy().copy() for p in model.parameters()]
+    if world > 1:
+        broadcast_parameters(model)
+        enable_sync_batchnorm(True)
+        idx = shard_batch(lens.tolist(), world)[rank]
+        feats, lens, texts, llens = take_shard(feats, lens, texts, llens, idx)
+    bucket = FlatGradBucket(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    hook = GradientClipping(clip_norm=50.0, skip_step_norm=1e7)
+    fused = FusedClipAdam.from_optimizer(opt, bucket, hook)
+    fd = feats.to(dev)
+    losses = []
+    for _ in range(3):
+        out, skip = train_step(model, opt, ((fd, lens, None, texts, llens), {}), hooks=[hook],
+                               bucket=bucket, fused=fused)
+        losses.append(float(out['loss'].detach()))
+    stats = fused.drain()
+    return dict(losses=losses, norms=[r[0] for r in stats], skipped=[r[2] for r in stats],
+                p0=p0, p=[p.detach().float().cpu().numpy() for p in model.parameters()])
+
+
+def test_two_rank_training_steps_equal_the_single_process():
+    """dp.train_step on two replicas (shards of 4 + 4 utterances, flat-bucket all-reduce, the clip /
+    skip decision and Adam on the device, BatchNorm statistics shared) against one process on
+    the 8 utterances: the summed losses, the global gradient norms the device step saw, and the
+    updates; and the replicas stay bit-identical."""
+    want = _dp_run(1, 0)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for a, b in zip(got[0]['p'], got[1]['p']):
+        assert np.array_equal(a, b)                      # same all-reduced gradient, same decision, same update
+    assert got[0]['norms'] == got[1]['norms'] and not any(got[0]['skipped'])
+    total = [a + b for a, b in zip(got[0]['losses'], got[1]['losses'])]
+    np.testing.assert_allclose(total, want['losses'], rtol=2e-4)
+    np.testing.assert_allclose(got[0]['norms'], want['norms'], rtol=2e-3)
+    d_want = np.concatenate([(x - y).ravel() for x, y in zip(want['p'], want['p0'])])
+    d_got = np.concatenate([(x - y).ravel() for x, y in zip(got[0]['p'], got[0]['p0'])])
+    assert np.linalg.norm(d_got - d_want) <= 0.05 * np.linalg.norm(d_want)
