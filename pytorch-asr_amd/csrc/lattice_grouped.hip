@@ -20,6 +20,7 @@
 // One workgroup per utterance; alpha / beta, the group sums and the gradient row
 // live in LDS; member lists are read from global memory (L2-resident, shared by
 // the whole batch).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/asr_amd.h"
 
@@ -169,6 +170,193 @@ __global__ __launch_bounds__(1024) void grouped_fwbw_kernel(GroupedParams p) {
             cur[n] = p.selfx[n] ? lse2(q, nxt[n]) : q;
         }
         __syncthreads();
+    }
+    if (p.logZ_bwd && tid == 0) p.logZ_bwd[b] = cur[0];   // logsumexp(alpha_0 + beta_0) (:476)
+}
+
+// The same scan with everything a frame needs already on the CU (round 3; the kernel above is
+// kept for graphs whose groups are wider than 64 states).  The first version spent ~10 k cycles
+// per frame and direction on one CU per utterance, almost all of it waiting: the member lists,
+// h / g / label / self-loop flags of every state and the frame's log-probs were fetched from
+// global memory inside the dependent chain, frame after frame.  Here a thread keeps the
+// description of its (<= SPT) states in registers, a lane of a group's 16-lane team keeps its
+// (<= 4) members of both lists in registers, and the log-probs / stored alphas of the NEXT
+// frame are loaded while the current one is computed.
+template <int SPT>
+__global__ __launch_bounds__(1024) void grouped_fwbw_fast_kernel(GroupedParams p) {
+    extern __shared__ float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    const int N = p.N, G = p.G, C = p.C;
+    float *a0 = smem;                    // [N] alpha / beta (current)
+    float *a1 = a0 + N;                  // [N] next / u = lp + beta
+    float *R = a1 + N;                   // [G]
+    float *row = R + ((G + 3) & ~3);     // [C] gradient row
+    float *red = row + ((C + 3) & ~3);   // [32]
+    int len = p.lens[b];
+    len = len < 0 ? 0 : (len > p.T ? p.T : len);
+    const size_t tstride = (size_t)p.B * C;
+    const float *lp_b = p.lp + (size_t)b * C;
+    float *grad_b = p.grad + (size_t)b * C;
+    const size_t astride = (size_t)p.B * N;
+    float *al_b = p.alphas + (size_t)b * N;
+
+    // this thread's states
+    int sh[SPT], sg[SPT], slab[SPT];
+    bool sv[SPT], sself[SPT], suniq[SPT];
+    float sterm[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+        const int n = tid + k * NT;
+        sv[k] = n < N;
+        const int nn = sv[k] ? n : 0;
+        sh[k] = p.h_of[nn]; sg[k] = p.g_of[nn]; slab[k] = p.label[nn];
+        sself[k] = p.selfx[nn] != 0; suniq[k] = p.uniq[nn] != 0;
+        sterm[k] = p.term[nn];
+    }
+    // this lane's members of its group (both lists)
+    const bool glane = tid < G * LPG;
+    const int grp = tid / LPG, gl = tid % LPG;
+    int mg[4], mh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = gl + LPG * j;
+        mg[j] = (glane && idx < p.Wg) ? p.mem_g[(size_t)grp * p.Wg + idx] : -1;
+        mh[j] = (glane && idx < p.Wh) ? p.mem_h[(size_t)grp * p.Wh + idx] : -1;
+    }
+    auto group_lse_reg = [&](const float *val, const int *mem) -> float {
+        float v[4], m = p.neg_inf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = mem[j] >= 0 ? val[mem[j]] : p.neg_inf;
+            m = fmaxf(m, v[j]);
+        }
+#pragma unroll
+        for (int o = LPG / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, LPG));
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += mem[j] >= 0 ? __expf(v[j] - m) : 0.f;
+#pragma unroll
+        for (int o = LPG / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, LPG);
+        return sum > 0.f ? m + __logf(sum) : p.neg_inf;
+    };
+    auto lpload = [&](int t, float *o) {
+        const float *lrow = lp_b + (size_t)t * tstride;
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) o[k] = sv[k] ? lrow[slab[k]] : 0.f;
+    };
+
+    for (int t = len; t < p.T; ++t)                       // fst_utils.py:448
+        for (int c = tid; c < C; c += NT) grad_b[(size_t)t * tstride + c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < SPT; ++k)
+        if (sv[k]) {
+            const int n = tid + k * NT;
+            const float v = n == 0 ? 0.f : p.neg_inf;     // start state 0 (fst_utils.py:246)
+            a0[n] = v;
+            al_b[n] = v;
+        }
+    for (int c = tid; c < C; c += NT) row[c] = 0.f;
+    float lpc[SPT], lpn[SPT];
+    if (len > 0) lpload(0, lpc);
+    __syncthreads();
+
+    // ---------------- forward ----------------
+    float *cur = a0, *nxt = a1;
+    for (int t = 0; t < len; ++t) {
+        if (t + 1 < len) lpload(t + 1, lpn);
+        if (glane) {
+            const float r = group_lse_reg(cur, mg);
+            if (gl == 0) R[grp] = r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPT; ++k)
+            if (sv[k]) {
+                const int n = tid + k * NT;
+                const float r = R[sh[k]];
+                const float v = lpc[k] + (sself[k] ? lse2(r, cur[n]) : r);
+                nxt[n] = v;
+                al_b[(size_t)(t + 1) * astride + n] = v;
+            }
+        __syncthreads();
+        float *tmp = cur; cur = nxt; nxt = tmp;
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) lpc[k] = lpn[k];
+    }
+    float logZ;
+    {
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < SPT; ++k)
+            if (sv[k]) m = fmaxf(m, cur[tid + k * NT] + sterm[k]);
+        m = block_max(m, red);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < SPT; ++k)
+            if (sv[k]) s += __expf(cur[tid + k * NT] + sterm[k] - m);
+        s = block_sum(s, red);
+        logZ = m + __logf(s);
+        if (tid == 0) p.logZ[b] = logZ;
+    }
+    __syncthreads();
+
+    // ---------------- backward ----------------
+    // cur = beta_{t+1}; nxt = u = lp_t[label] + beta_{t+1}
+#pragma unroll
+    for (int k = 0; k < SPT; ++k)
+        if (sv[k]) cur[tid + k * NT] = sterm[k];
+    float ac[SPT], an[SPT];
+    auto aload = [&](int t, float *o) {                    // alpha after t frames
+        const float *arow = al_b + (size_t)t * astride;
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) o[k] = sv[k] ? arow[tid + k * NT] : 0.f;
+    };
+    if (len > 0) {
+        lpload(len - 1, lpc);
+        aload(len, ac);
+    }
+    __syncthreads();
+    for (int t = len - 1; t >= 0; --t) {
+        if (t > 0) {
+            lpload(t - 1, lpn);
+            aload(t, an);
+        }
+#pragma unroll
+        for (int k = 0; k < SPT; ++k)
+            if (sv[k]) {
+                const int n = tid + k * NT;
+                const float bt = cur[n];
+                nxt[n] = lpc[k] + bt;
+                // posterior of being in state n after frame t
+                const float o = __expf(ac[k] + bt - logZ);
+                if (o != 0.f) {
+                    if (suniq[k]) row[slab[k]] = o;
+                    else atomicAdd(&row[slab[k]], o);
+                }
+            }
+        __syncthreads();
+        if (glane) {
+            const float r = group_lse_reg(nxt, mh);
+            if (gl == 0) R[grp] = r;
+        }
+        {   // the finished gradient row leaves (and is cleared for the next frame)
+            float *gout = grad_b + (size_t)t * tstride;
+            for (int c = tid; c < C; c += NT) {
+                gout[c] = row[c];
+                row[c] = 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPT; ++k)
+            if (sv[k]) {
+                const int n = tid + k * NT;
+                const float q = R[sg[k]];
+                cur[n] = sself[k] ? lse2(q, nxt[n]) : q;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) { lpc[k] = lpn[k]; ac[k] = an[k]; }
     }
     if (p.logZ_bwd && tid == 0) p.logZ_bwd[b] = cur[0];   // logsumexp(alpha_0 + beta_0) (:476)
 }
@@ -345,6 +533,15 @@ extern "C" int asr_lattice_grouped_fwbw_f32(
         return ASR_EUNSUPPORTED;
     int nt = N >= 1024 ? 1024 : round_up64(N);
     if (nt < G * LPG) nt = round_up64(G * LPG);
+    const int spt = (N + nt - 1) / nt;
+    static const bool fast_on = !(getenv("ASR_GROUPED_FAST") && getenv("ASR_GROUPED_FAST")[0] == '0');
+    if (fast_on && Wg <= 4 * LPG && Wh <= 4 * LPG && spt <= 4 && nt <= 1024 && lds <= 64 * 1024) {
+        void (*kern)(GroupedParams) = spt <= 1 ? grouped_fwbw_fast_kernel<1>
+                                      : spt == 2 ? grouped_fwbw_fast_kernel<2>
+                                      : spt == 3 ? grouped_fwbw_fast_kernel<3> : grouped_fwbw_fast_kernel<4>;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, (hipStream_t)stream, p);
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
     hipLaunchKernelGGL(grouped_fwbw_kernel, dim3(B), dim3(nt), lds, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
 }
