@@ -541,6 +541,24 @@ int asr_beam_step_f32(const float *logits, const float *scores_in, float *scores
  * (or *step_in when skipped); step_in != step_out (the caller alternates two words).
  * stats [4] = {norm, clipped, skipped, err} as floats, for the host to read when it likes.
  */
+/*
+ * asr_lattice_fwbw_f32 with the occupancies written times grad_sign (+1 or -1) (ABI v20): a
+ * decoder that needs -logZ (the numerator of FSTDecoder.get_fst_loss, advanced_decoder.py:486-496)
+ * asks for -1 and receives the gradient of what it uses; the backward pass of PathLogSumExp
+ * (fst_utils.py:482-485: grad_output[None, :, None] * grads) then multiplies by +1 —
+ * asr_scale_rows_f32 (x [T,B,C] *= scale [B] in place) leaves utterances whose factor is exactly 1
+ * untouched, so the usual backward pass makes no pass over the [T,B,C] tensor at all (1.6 GB at
+ * C = 2401, 512 utterances).  out_logZ is +logZ either way.
+ */
+int asr_lattice_fwbw_signed_f32(const float *lp, int T, int B, int C, const int32_t *lens,
+                                const int32_t *src_in, const int32_t *il_in, const float *w_in,
+                                const float *term, const int32_t *dst_out, const int32_t *il_out,
+                                const float *w_out, int N, int Kin, int Kout, int Bg, float neg_inf,
+                                float grad_sign, float *out_logZ, float *out_grad,
+                                float *out_logZ_bwd, void *workspace, int64_t workspace_bytes,
+                                void *stream);
+int asr_scale_rows_f32(float *x, int T, int B, int C, const float *scale, void *stream);
+
 typedef struct AsrAdamChunk {
     void *param;
     uint32_t flat_offset;

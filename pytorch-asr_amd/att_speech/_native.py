@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -34,6 +34,10 @@ _SIGNATURES = {
     'asr_lattice_fwbw_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp,
                                   _vp, _i64, _vp]),
+    'asr_lattice_fwbw_signed_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp,
+                                         _vp, _i64, _vp]),
+    'asr_scale_rows_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'asr_lattice_fwbw_band_supported': (_i, [_i] * 7),
     'asr_lattice_fwbw_band_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp,
@@ -279,8 +283,19 @@ def _band_policy_record(device, B):
     st['pending'] = (host, ev, st['launched'])
 
 
-def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
-    """asr_lattice_fwbw_f32: returns (logZ [B], grad [T,B,C], logZ_bwd|None)."""
+def scale_rows_(x, scale):
+    """asr_scale_rows_f32: x [T,B,C] *= scale [B] in place; utterances whose factor is exactly 1
+    are not touched."""
+    x = _dev(x, torch.float32, 'x')
+    scale = _dev(scale.to(torch.float32), torch.float32, 'scale')
+    T, B, C = x.shape
+    check(lib().asr_scale_rows_f32(_p(x), T, B, C, _p(scale), _stream()), 'asr_scale_rows_f32')
+    return x
+
+
+def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False, grad_sign=1.0):
+    """asr_lattice_fwbw_f32: returns (logZ [B], grad [T,B,C], logZ_bwd|None); grad_sign = -1:
+    the occupancies come back negated (asr_lattice_fwbw_signed_f32: the gradient of -logZ)."""
     lp = _dev(lp, torch.float32, 'log_probs')
     lens = _dev(lens, torch.int32, 'act_lens')
     T, B, C = lp.shape
@@ -318,6 +333,11 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False):
     if use_band:
         check(L.asr_lattice_fwbw_band_f32(*args, _p(_band_counter(lp.device)[0]), _stream()),
               'asr_lattice_fwbw_band_f32')
+        if grad_sign != 1.0:            # (mono-character alphabets: a pass over 50 MB)
+            grad.mul_(grad_sign)
+    elif grad_sign != 1.0:
+        check(L.asr_lattice_fwbw_signed_f32(*(args[:17] + (float(grad_sign),) + args[17:]), _stream()),
+              'asr_lattice_fwbw_signed_f32')
     else:
         check(L.asr_lattice_fwbw_f32(*args, _stream()), 'asr_lattice_fwbw_f32')
     if hook is not None:

@@ -164,11 +164,19 @@ def _device_grouped(graph_matrices, device):
 class PathLogSumExp(torch.autograd.Function):
     """Forward-backward in the log semiring; same contract as the reference's
     PathLogSumExp (fst_utils.py:400-488): returns +logZ per utterance, the
-    gradient is computed inside forward and scaled in backward."""
+    gradient is computed inside forward and scaled in backward.
+
+    `negate` (an extension): return -logZ, the quantity a loss uses
+    (advanced_decoder.py:486-496), with the occupancies stored negated by the kernel.  The
+    backward pass then scales IN PLACE by the incoming gradient, which in a training step is
+    exactly 1 for every utterance, and `asr_scale_rows_f32` skips those: the reference's
+    `grad_output[None, :, None] * grads` (fst_utils.py:482-485) was a pass over the whole
+    [T,B,C] tensor — 1.6 GB, 0.5 ms, for a bi-character alphabet at 512 utterances."""
 
     @staticmethod
-    def forward(ctx, log_probs, act_lens, graph_matrices, neg_inf=-np.inf):
+    def forward(ctx, log_probs, act_lens, graph_matrices, neg_inf=-np.inf, negate=False):
         log_probs = log_probs.detach()
+        sign = -1.0 if negate else 1.0
         _assert_sorted(act_lens)
         if not np.isfinite(neg_inf):
             neg_inf = NEG_INF
@@ -176,18 +184,26 @@ class PathLogSumExp(torch.autograd.Function):
         grouped = _device_grouped(graph_matrices, log_probs.device)
         if grouped is not None:                   # closed-form decoding graph
             log_cost, grads, _ = _native.grouped_fwbw(log_probs, lens, grouped, neg_inf)
+            if negate:
+                grads.neg_()
             ctx.grads = grads
-            return log_cost
+            return -log_cost if negate else log_cost
         graph = _device_graph(graph_matrices, log_probs.device)
         if graph.dst_out is None:
             raise AssertionError("PathLogSumExp needs the 8 graph matrices")
-        log_cost, grads, _ = _native.lattice_fwbw(log_probs, lens, graph, neg_inf)
+        log_cost, grads, _ = _native.lattice_fwbw(log_probs, lens, graph, neg_inf, grad_sign=sign)
         ctx.grads = grads
-        return log_cost
+        return -log_cost if negate else log_cost
 
     @staticmethod
     def backward(ctx, grad_output):
-        return (grad_output[None, :, None] * ctx.grads, None, None, None)
+        grads, ctx.grads = ctx.grads, None
+        if grads is None:
+            raise RuntimeError("PathLogSumExp: backward a second time (the occupancies are scaled "
+                               "in place and released after the first)")
+        if grads.is_cuda and grads.dtype == torch.float32 and grads.dim() == 3:
+            return (_native.scale_rows_(grads, grad_output), None, None, None, None)
+        return (grad_output[None, :, None] * grads, None, None, None, None)
 
 
 path_logsumexp = PathLogSumExp.apply
@@ -232,9 +248,18 @@ def viterbi_path(log_probs, act_lens, graph_matrices, neg_inf=NEG_INF):
 
 
 def path_reduction(log_probs, act_lens, graph_matrices, red_kind='logsumexp',
-                   neg_inf=NEG_INF):
+                   neg_inf=NEG_INF, negate=False):
     """Sum (logsumexp) or max over all paths through per-utterance graphs.
-    Same dispatch as the reference (fst_utils.py:322-397)."""
+    Same dispatch as the reference (fst_utils.py:322-397).  `negate` (an extension): the
+    negated result, cheaper than negating outside for the logsumexp reductions that carry
+    their own gradient (see PathLogSumExp)."""
+    if negate:
+        if red_kind in ('logsumexp_fwb', 'logsumexp', 'logsumexp_autodiff') and log_probs.is_cuda and \
+                (isinstance(graph_matrices, _native.Graph) or red_kind == 'logsumexp_fwb' or
+                 len(graph_matrices) == 8):
+            _assert_sorted(act_lens)
+            return path_logsumexp(log_probs, act_lens, graph_matrices, NEG_INF, True)
+        return -path_reduction(log_probs, act_lens, graph_matrices, red_kind, neg_inf)
     if isinstance(graph_matrices, _native.Graph):       # device-built lattice
         if red_kind in ('logsumexp_fwb', 'logsumexp', 'logsumexp_autodiff'):
             return path_logsumexp(log_probs, act_lens, graph_matrices, NEG_INF)

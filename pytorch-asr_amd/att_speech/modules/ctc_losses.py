@@ -109,7 +109,7 @@ def ctc_fst_loss(acts, labels, act_lens, label_lens,
         graph_gen = _graph_gen(S, context_order, **gg_kwargs)
         labels_b = _labels_to_batch(labels, label_lens)
         graph_matrices = graph_gen.get_training_matrices_batch(labels_b, label_lens)
-    return -path_reduction(log_probs, act_lens, graph_matrices, neg_inf=neg_inf)
+    return path_reduction(log_probs, act_lens, graph_matrices, neg_inf=neg_inf, negate=True)
 
 
 def ctc_loss(acts, labels, act_lens, label_lens,
@@ -185,7 +185,7 @@ def ctc_raw_loss_batch(acts, labels, act_lens, label_lens,
                            use_contextual_blanks=True)
     graph_matrices = graph_gen.get_training_matrices_batch(
         _labels_to_batch(labels, label_lens), label_lens)
-    return -path_reduction(log_probs, act_lens, graph_matrices)
+    return path_reduction(log_probs, act_lens, graph_matrices, negate=True)
 
 
 # the reference's per-utterance Python loop (:521-560) computes the same values

@@ -626,8 +626,8 @@ class FSTDecoder(_ProjectionDecoder):
             shifted, max_sum = _NormaliseShift.apply(logits, lens_dev)   # (:444-452) + (:479-484)
         else:
             shifted, max_sum = _SubRowMax.apply(logits, lens_dev)        # (:479-484)
-        num = -fst_utils.path_reduction(shifted, encoded_lens, numerator,
-                                        red_kind=self.numerator_red, neg_inf=gg.nc_weight)
+        num = fst_utils.path_reduction(shifted, encoded_lens, numerator, red_kind=self.numerator_red,
+                                       neg_inf=gg.nc_weight, negate=True)
         if self.denominator_red == 'none':
             den = max_sum
         else:

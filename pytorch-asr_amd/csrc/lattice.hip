@@ -30,6 +30,7 @@ struct FwbwParams {
     float *logZ, *grad, *logZ_bwd;
     float *alphas;  // workspace, [T+2,B,roundup(N,64)] for the meet-in-the-middle kernels
     unsigned *redo; // band kernel: running count of utterances redone by the fallback body, or null
+    float gsign;    // the posteriors are written times this (+1; -1: the gradient of -logZ)
 };
 
 // KR > 0: every thread owns ONE state (N <= blockDim) and keeps its <= KR
@@ -187,7 +188,7 @@ __device__ __forceinline__ void lattice_fwbw_generic_body(const FwbwParams &p, f
 #pragma unroll
                 for (int k = 0; k < KR; ++k) {
                     if (r_w[k] > half_inf) {
-                        float o = __expf(v[k] + a);
+                        float o = __expf(v[k] + a) * p.gsign;
                         if (o != 0.f) atomicAdd(&rw[r_il[k]], o);
                     }
                 }
@@ -204,7 +205,7 @@ __device__ __forceinline__ void lattice_fwbw_generic_body(const FwbwParams &p, f
                     float v = w + bt[dst_out[i]] + lrow[il];
                     acc.add(v);
                     if (w > half_inf) {
-                        float o = __expf(v + a);
+                        float o = __expf(v + a) * p.gsign;
                         if (o != 0.f) atomicAdd(&rw[il], o);
                     }
                 }
@@ -438,7 +439,7 @@ __device__ __forceinline__ void lattice_fwbw_mitm_body(const FwbwParams &p, floa
 #pragma unroll
                         for (int k = 0; k < KR; ++k) {
                             if (r_w[k] > half_inf) {
-                                float o = __expf(v[k] + a);
+                                float o = __expf(v[k] + a) * p.gsign;
 #ifndef ASR_ABLATE_NOATOMIC
                                 if (o != 0.f) atomicAdd(&rw[r_il[k]], o);
 #else
@@ -871,7 +872,7 @@ void lattice_fwbw_sl_kernel(FwbwParams p) {
                 *(v ? row + rf + ci : ldump) = 0.f;
                 st(gradR, v ? gcur : OOB, fl);
             }
-            float gam = __builtin_amdgcn_exp2f((isB ? breg : val1) + wv - logZ2);
+            float gam = __builtin_amdgcn_exp2f((isB ? breg : val1) + wv - logZ2) * p.gsign;
             if (!own || !act) gam = 0.f;
             gprev = gam;
             if (FL == 1) {
@@ -1184,17 +1185,19 @@ extern "C" int64_t asr_lattice_fwbw_workspace_bytes(int T, int B, int C, int N) 
     return (int64_t)(T + 2) * B * (H + 64) * (int64_t)sizeof(float) + 256;
 }
 
-extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
+extern "C" int asr_lattice_fwbw_signed_f32(const float *lp, int T, int B, int C,
                                     const int32_t *lens,
                                     const int32_t *src_in, const int32_t *il_in,
                                     const float *w_in, const float *term,
                                     const int32_t *dst_out, const int32_t *il_out,
                                     const float *w_out,
                                     int N, int Kin, int Kout, int Bg, float neg_inf,
+                                    float grad_sign,
                                     float *out_logZ, float *out_grad,
                                     float *out_logZ_bwd,
                                     void *workspace, int64_t workspace_bytes,
                                     void *stream) {
+    if (!(grad_sign == 1.f || grad_sign == -1.f)) return ASR_EINVAL;
     if (T < 0 || B < 0 || C <= 0 || N <= 0 || Kin <= 0 || Kout <= 0) return ASR_EINVAL;
     if (Bg != 1 && Bg != B) return ASR_EINVAL;            // fst_utils.py:406
     if (B == 0) return ASR_OK;
@@ -1215,6 +1218,7 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
     p.redo = nullptr;
+    p.gsign = grad_sign;
 
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
@@ -1257,6 +1261,22 @@ extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
     }
     hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, s, p);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
+                                    const int32_t *lens,
+                                    const int32_t *src_in, const int32_t *il_in,
+                                    const float *w_in, const float *term,
+                                    const int32_t *dst_out, const int32_t *il_out,
+                                    const float *w_out,
+                                    int N, int Kin, int Kout, int Bg, float neg_inf,
+                                    float *out_logZ, float *out_grad,
+                                    float *out_logZ_bwd,
+                                    void *workspace, int64_t workspace_bytes,
+                                    void *stream) {
+    return asr_lattice_fwbw_signed_f32(lp, T, B, C, lens, src_in, il_in, w_in, term, dst_out, il_out, w_out,
+                                       N, Kin, Kout, Bg, neg_inf, 1.f, out_logZ, out_grad, out_logZ_bwd,
+                                       workspace, workspace_bytes, stream);
 }
 
 extern "C" int64_t asr_lattice_viterbi_workspace_bytes(int T, int B, int N) {
@@ -1350,6 +1370,7 @@ extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
     p.redo = nullptr;
+    p.gsign = 1.f;
     // the in-kernel fallback (lattice_fwbw_generic_body<0>) needs 2 Npad + 2 Cpad + 64 words
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)band::LDS_WORDS * sizeof(float);

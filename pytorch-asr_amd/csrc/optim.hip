@@ -103,7 +103,32 @@ __global__ __launch_bounds__(TPB) void adam_clip_step_kernel(AdamParams p) {
     }
 }
 
+// x[t, b, :] *= scale[b], in place; utterances whose factor is exactly 1 are not touched (their
+// workgroups leave after one load): the usual case of PathLogSumExp.backward, fst_utils.py:482-485.
+__global__ __launch_bounds__(TPB) void scale_rows_kernel(float *x, int T, int B, int C, const float *scale,
+                                                         int tchunk) {
+    const int b = blockIdx.y;
+    const float sc = scale[b];
+    if (sc == 1.f) return;
+    const int t0 = blockIdx.x * tchunk;
+    const int t1 = t0 + tchunk < T ? t0 + tchunk : T;
+    for (int t = t0; t < t1; ++t) {
+        float *row = x + ((size_t)t * B + b) * C;
+        for (int c = threadIdx.x; c < C; c += TPB) row[c] *= sc;
+    }
+}
+
 }  // namespace
+
+extern "C" int asr_scale_rows_f32(float *x, int T, int B, int C, const float *scale, void *stream) {
+    if (T < 0 || B < 0 || C <= 0 || (!x && T > 0 && B > 0) || !scale) return ASR_EINVAL;
+    if (T == 0 || B == 0) return ASR_OK;
+    if (B > 65535) return ASR_EUNSUPPORTED;
+    const int tchunk = 8;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((T + tchunk - 1) / tchunk, B), dim3(TPB), 0,
+                       (hipStream_t)stream, x, T, B, C, scale, tchunk);
+    return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
 
 extern "C" int asr_adam_chunk_elems(void) { return CHUNK; }
 

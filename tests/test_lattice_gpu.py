@@ -702,3 +702,31 @@ def test_fused_normalise_and_shift(T, B, C):
     want.backward(dy.double())
     dx = _native.log_softmax_shift_bwd(y, nls, dy.to(d))
     np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize('order,S', [(1, 49), (2, 7)])
+def test_negated_reduction_and_in_place_backward(order, S):
+    """path_reduction(negate=True) = -path_reduction(): the kernels write the occupancies
+    negated (asr_lattice_fwbw_signed_f32; the band kernel's small tensor is negated after the
+    launch), PathLogSumExp.backward scales in place and asr_scale_rows_f32 leaves utterances
+    with factor 1 alone.  Values and gradients against the plain form, with unit and non-unit
+    incoming gradients."""
+    from att_speech import fst_utils as P
+    lp, lens, mats = _random_case(order=order, S=S, T=60, B=5, Lmax=14, seed=77)
+    x = torch.from_numpy(lp).to(dev())
+    tm = to_t(mats)
+    w = torch.tensor([1.0, 1.0, -0.5, 1.0, 3.0], device=dev())
+    for weights in (None, w):
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        ya = -P.path_reduction(a, torch.from_numpy(lens), tm)
+        yb = P.path_reduction(b, torch.from_numpy(lens), tm, negate=True)
+        np.testing.assert_array_equal(ya.detach().cpu().numpy(), yb.detach().cpu().numpy())
+        (ya.sum() if weights is None else (ya * weights).sum()).backward()
+        (yb.sum() if weights is None else (yb * weights).sum()).backward()
+        np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), rtol=0, atol=0)
+    with pytest.raises(RuntimeError):
+        c = x.clone().requires_grad_(True)
+        y = P.path_reduction(c, torch.from_numpy(lens), tm, negate=True).sum()
+        y.backward(retain_graph=True)
+        y.backward()
