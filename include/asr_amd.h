@@ -91,9 +91,10 @@ int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
  * CTCGraphGen builds for mono-character transcripts (fst_utils.py:603-613; the `2 L + 1`
  * CTC chain).  One wave per direction keeps four consecutive states per lane (no
  * transcendental, no LDS and no barrier on the recurrence), alpha / beta are block floating
- * point (one binary exponent per lane, rescaled by exact powers of two), every posterior row
- * is normalised by its own total; only every second alpha / beta row goes through the
- * workspace (the consumer recomputes the one in between).
+ * point (one binary exponent per lane, rescaled by exact powers of two), the posterior rows
+ * are normalised by Z (every group of four rows is checked to sum to four); only every second
+ * alpha / beta row goes through the workspace (the consumer recomputes the one in between).
+ *   grad_sign   +1, or -1 for the occupancies of -logZ (see asr_lattice_fwbw_signed_f32; ABI v20)
  *   redo_count  device word of the caller or NULL: incremented once per utterance that the
  *               log-domain body had to redo; never reset by the library (a running counter:
  *               the caller takes differences).  (ABI v17)
@@ -111,7 +112,7 @@ int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
                               const float *w_in, const float *term,
                               const int32_t *dst_out, const int32_t *il_out,
                               const float *w_out,
-                              int N, int Kin, int Kout, int Bg, float neg_inf,
+                              int N, int Kin, int Kout, int Bg, float neg_inf, float grad_sign,
                               float *out_logZ, float *out_grad,
                               float *out_logZ_bwd,
                               void *workspace, int64_t workspace_bytes,

@@ -40,7 +40,7 @@ _SIGNATURES = {
     'asr_scale_rows_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'asr_lattice_fwbw_band_supported': (_i, [_i] * 7),
     'asr_lattice_fwbw_band_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                       _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp,
+                                       _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp,
                                        _vp, _i64, _vp, _vp]),
     'asr_lattice_viterbi_workspace_bytes': (_i64, [_i, _i, _i]),
     'asr_lattice_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
@@ -330,14 +330,12 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False, grad_sign
             _p(graph.w_in), _p(graph.term), _p(graph.dst_out), _p(graph.il_out),
             _p(graph.w_out), graph.N, graph.Kin, graph.Kout, graph.Bg,
             float(neg_inf), _p(logZ), _p(grad), _p(zb), _p(ws), nbytes)
+    sargs = args[:17] + (float(grad_sign),) + args[17:]
     if use_band:
-        check(L.asr_lattice_fwbw_band_f32(*args, _p(_band_counter(lp.device)[0]), _stream()),
+        check(L.asr_lattice_fwbw_band_f32(*sargs, _p(_band_counter(lp.device)[0]), _stream()),
               'asr_lattice_fwbw_band_f32')
-        if grad_sign != 1.0:            # (mono-character alphabets: a pass over 50 MB)
-            grad.mul_(grad_sign)
     elif grad_sign != 1.0:
-        check(L.asr_lattice_fwbw_signed_f32(*(args[:17] + (float(grad_sign),) + args[17:]), _stream()),
-              'asr_lattice_fwbw_signed_f32')
+        check(L.asr_lattice_fwbw_signed_f32(*sargs, _stream()), 'asr_lattice_fwbw_signed_f32')
     else:
         check(L.asr_lattice_fwbw_f32(*args, _stream()), 'asr_lattice_fwbw_f32')
     if hook is not None:

@@ -1347,7 +1347,7 @@ extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
                                          const float *w_in, const float *term,
                                          const int32_t *dst_out, const int32_t *il_out,
                                          const float *w_out,
-                                         int N, int Kin, int Kout, int Bg, float neg_inf,
+                                         int N, int Kin, int Kout, int Bg, float neg_inf, float grad_sign,
                                          float *out_logZ, float *out_grad,
                                          float *out_logZ_bwd,
                                          void *workspace, int64_t workspace_bytes, uint32_t *redo_count,
@@ -1370,7 +1370,8 @@ extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
     p.redo = nullptr;
-    p.gsign = 1.f;
+    if (!(grad_sign == 1.f || grad_sign == -1.f)) return ASR_EINVAL;
+    p.gsign = grad_sign;
     // the in-kernel fallback (lattice_fwbw_generic_body<0>) needs 2 Npad + 2 Cpad + 64 words
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)band::LDS_WORDS * sizeof(float);
