@@ -95,6 +95,10 @@ int asr_lattice_fwbw_f32(const float *lp, int T, int B, int C,
  * are normalised by Z (every group of four rows is checked to sum to four); only every second
  * alpha / beta row goes through the workspace (the consumer recomputes the one in between).
  *   grad_sign   +1, or -1 for the occupancies of -logZ (see asr_lattice_fwbw_signed_f32; ABI v20)
+ *   ctc_labels  NULL, or the transcripts [B, ctc_lmax] (+ ctc_label_lens [B]) the graph matrices were
+ *               built from by asr_ctc_graph_build with context_order 1 (N >= 2 ctc_lmax + 1): the
+ *               kernel then writes the chain down from the labels and reads the matrices only for
+ *               utterances the log-domain body has to redo (ABI v21)
  *   redo_count  device word of the caller or NULL: incremented once per utterance that the
  *               log-domain body had to redo; never reset by the library (a running counter:
  *               the caller takes differences).  (ABI v17)
@@ -116,7 +120,9 @@ int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
                               float *out_logZ, float *out_grad,
                               float *out_logZ_bwd,
                               void *workspace, int64_t workspace_bytes,
-                              uint32_t *redo_count, void *stream);
+                              uint32_t *redo_count,
+                              const int32_t *ctc_labels, const int32_t *ctc_label_lens, int ctc_lmax,
+                              void *stream);
 
 /*
  * Alpha-only scan: path_reduction's autodiff branch evaluated forward

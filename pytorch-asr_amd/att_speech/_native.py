@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -41,7 +41,7 @@ _SIGNATURES = {
     'asr_lattice_fwbw_band_supported': (_i, [_i] * 7),
     'asr_lattice_fwbw_band_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp,
-                                       _vp, _i64, _vp, _vp]),
+                                       _vp, _i64, _vp, _vp, _vp, _i, _vp]),
     'asr_lattice_viterbi_workspace_bytes': (_i64, [_i, _i, _i]),
     'asr_lattice_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _f, _i, _vp, _vp, _vp, _i64,
@@ -187,7 +187,7 @@ class Graph(object):
     """Device-resident int32/f32 copy of the reference's 4 or 8 padded graph
     matrices (fst_utils.py:222-294,491-521)."""
     __slots__ = ('src_in', 'il_in', 'w_in', 'term', 'dst_out', 'il_out',
-                 'w_out', 'Bg', 'N', 'Kin', 'Kout', 'band')
+                 'w_out', 'Bg', 'N', 'Kin', 'Kout', 'band', 'ctc_labels')
 
     def __init__(self, graph_matrices, device):
         # band: every state n is entered only from {n, n-1, n-2} with weights <= 0 (the CTC
@@ -195,6 +195,7 @@ class Graph(object):
         # build_ctc_graph, or found here on the host when the matrices arrive as CPU tensors
         # (the data workers' hand-over, fst_utils.py:491-521); the kernel re-checks per utterance.
         self.band = False
+        self.ctc_labels = None      # (labels [B,Lmax] i32, lens [B] i32) when built from them (order 1)
         if graph_matrices is None:          # filled in by build_ctc_graph
             return
         gm = list(graph_matrices)
@@ -332,7 +333,12 @@ def lattice_fwbw(lp, lens, graph, neg_inf=-1e20, want_bwd_total=False, grad_sign
             float(neg_inf), _p(logZ), _p(grad), _p(zb), _p(ws), nbytes)
     sargs = args[:17] + (float(grad_sign),) + args[17:]
     if use_band:
-        check(L.asr_lattice_fwbw_band_f32(*sargs, _p(_band_counter(lp.device)[0]), _stream()),
+        cl = getattr(graph, 'ctc_labels', None)
+        if cl is not None and os.environ.get('ASR_BAND_LABELS', '1') == '0':
+            cl = None
+        check(L.asr_lattice_fwbw_band_f32(*sargs, _p(_band_counter(lp.device)[0]),
+                                          _p(cl[0]) if cl else None, _p(cl[1]) if cl else None,
+                                          int(cl[0].shape[1]) if cl else 0, _stream()),
               'asr_lattice_fwbw_band_f32')
     elif grad_sign != 1.0:
         check(L.asr_lattice_fwbw_signed_f32(*sargs, _stream()), 'asr_lattice_fwbw_signed_f32')
@@ -728,6 +734,8 @@ def build_ctc_graph(labels, label_lens, num_symbols, context_order,
     g.term = torch.empty((B, N), dtype=torch.float32, device=dev)
     g.Bg, g.N, g.Kin, g.Kout = B, N, 3, 3
     g.band = True        # the 2 L + 1 chain in natural state order, both context orders
+    # mono-character chains: the band kernel writes the chain down from the transcript itself
+    g.ctc_labels = (labels, label_lens) if int(context_order) == 1 and Lmax > 0 else None
     check(lib().asr_ctc_graph_build(
         _p(labels), _p(label_lens), B, Lmax, int(num_symbols), int(context_order),
         int(bool(allow_nonblank_selfloops)), int(bool(use_contextual_blanks)),

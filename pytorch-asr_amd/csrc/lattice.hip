@@ -31,6 +31,8 @@ struct FwbwParams {
     float *alphas;  // workspace, [T+2,B,roundup(N,64)] for the meet-in-the-middle kernels
     unsigned *redo; // band kernel: running count of utterances redone by the fallback body, or null
     float gsign;    // the posteriors are written times this (+1; -1: the gradient of -logZ)
+    const int32_t *ctc_labels, *ctc_label_lens;   // band kernel: the transcripts [B, ctc_lmax] the graphs
+    int ctc_lmax;                                 // were built from (context order 1), or null
 };
 
 // KR > 0: every thread owns ONE state (N <= blockDim) and keeps its <= KR
@@ -1219,6 +1221,7 @@ extern "C" int asr_lattice_fwbw_signed_f32(const float *lp, int T, int B, int C,
     p.alphas = (float *)workspace;
     p.redo = nullptr;
     p.gsign = grad_sign;
+    p.ctc_labels = p.ctc_label_lens = nullptr; p.ctc_lmax = 0;
 
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)(2 * Npad + 2 * Cpad + 64) * sizeof(float);
@@ -1351,6 +1354,7 @@ extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
                                          float *out_logZ, float *out_grad,
                                          float *out_logZ_bwd,
                                          void *workspace, int64_t workspace_bytes, uint32_t *redo_count,
+                                         const int32_t *ctc_labels, const int32_t *ctc_label_lens, int ctc_lmax,
                                          void *stream) {
     if (T < 0 || B < 0 || C <= 0 || N <= 0 || Kin <= 0 || Kout <= 0) return ASR_EINVAL;
     if (Bg != 1 && Bg != B) return ASR_EINVAL;
@@ -1372,6 +1376,8 @@ extern "C" int asr_lattice_fwbw_band_f32(const float *lp, int T, int B, int C,
     p.redo = nullptr;
     if (!(grad_sign == 1.f || grad_sign == -1.f)) return ASR_EINVAL;
     p.gsign = grad_sign;
+    if (ctc_labels && (!ctc_label_lens || ctc_lmax < 0 || 2 * ctc_lmax + 1 > N)) return ASR_EINVAL;
+    p.ctc_labels = ctc_labels; p.ctc_label_lens = ctc_labels ? ctc_label_lens : nullptr; p.ctc_lmax = ctc_lmax;
     // the in-kernel fallback (lattice_fwbw_generic_body<0>) needs 2 Npad + 2 Cpad + 64 words
     const int Npad = (N + 3) & ~3, Cpad = (C + 3) & ~3;
     size_t lds = (size_t)band::LDS_WORDS * sizeof(float);

@@ -730,3 +730,37 @@ def test_negated_reduction_and_in_place_backward(order, S):
         y = P.path_reduction(c, torch.from_numpy(lens), tm, negate=True).sum()
         y.backward(retain_graph=True)
         y.backward()
+
+
+def test_band_kernel_from_labels_is_the_band_kernel_from_matrices(oracle_lib, monkeypatch):
+    """Graphs built on the device from the transcripts (asr_ctc_graph_build, context order 1)
+    carry the transcripts along: the band kernel then writes the CTC chain down from the labels
+    instead of reading and checking the matrices.  Same bits as from the matrices, and the
+    oracle's logZ on the host-built matrices of the same transcripts; repeated labels (no skip
+    arc), an empty transcript and a one-label one included."""
+    from att_speech import _native
+    from att_speech import fst_utils as P
+    rng = np.random.default_rng(91)
+    B, T, S, Lmax = 7, 80, 49, 30
+    llens = np.array([30, 21, 12, 30, 1, 0, 7], np.int64)
+    labs = rng.integers(2, S, size=(B, Lmax))
+    labs[3, 5:12] = labs[3, 5]                          # a run of one symbol
+    lens = np.array([80, 80, 77, 75, 70, 64, 61], np.int32)
+    lp = torch.log_softmax(torch.from_numpy(rng.standard_normal((T, B, S)).astype(np.float32) * 2), -1)
+    d = dev()
+    g = _native.build_ctc_graph(torch.from_numpy(labs.astype(np.int32)).to(d),
+                                torch.from_numpy(llens.astype(np.int32)).to(d), S, 1)
+    assert g.ctc_labels is not None and g.band
+    x, tl = lp.to(d), torch.from_numpy(lens).to(d)
+    monkeypatch.setenv('ASR_LATTICE_BAND', '2')
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('ASR_BAND_LABELS', flag)
+        logZ, grad, zb = _native.lattice_fwbw(x, tl, g, -1e20, want_bwd_total=True)
+        out[flag] = (logZ.cpu().numpy(), grad.cpu().numpy(), zb.cpu().numpy())
+    for a, b_ in zip(out['1'], out['0']):
+        np.testing.assert_array_equal(a, b_)
+    mats = [m.numpy() for m in P.CTCGraphGen(context_order=1, num_symbols=S).get_training_matrices_batch(labs, llens)]
+    want = oracle_lib.path_logsumexp(lp.numpy(), lens, mats)
+    np.testing.assert_allclose(out['1'][0], want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
+    assert_posteriors(out['1'][1], want['grad'], lp.numpy(), lens, mats, oracle_lib)

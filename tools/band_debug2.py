@@ -26,7 +26,7 @@ nbytes = L.asr_lattice_fwbw_workspace_bytes(Tn, B, C, g.N)
 ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=d)
 p = _native._p
 _native.check(L.asr_lattice_fwbw_band_f32(p(lpt), Tn, B, C, p(lt), p(g.src_in), p(g.il_in), p(g.w_in), p(g.term),
-    p(g.dst_out), p(g.il_out), p(g.w_out), g.N, g.Kin, g.Kout, g.Bg, -1e20, 1.0, p(logZ), p(grad), p(zb), p(ws), nbytes, None,
+    p(g.dst_out), p(g.il_out), p(g.w_out), g.N, g.Kin, g.Kout, g.Bg, -1e20, 1.0, p(logZ), p(grad), p(zb), p(ws), nbytes, None, None, None, 0,
     _native._stream()), 'band')
 torch.cuda.synchronize()
 ws = ws.cpu().numpy()

@@ -21,7 +21,7 @@ ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=d)
 p = _native._p
 for _ in range(3):
     _native.check(L.asr_lattice_fwbw_band_f32(p(lp), T, B, C, p(tl), p(g.src_in), p(g.il_in), p(g.w_in), p(g.term),
-        p(g.dst_out), p(g.il_out), p(g.w_out), g.N, g.Kin, g.Kout, g.Bg, -1e20, 1.0, p(logZ), p(grad), None, p(ws), nbytes, None,
+        p(g.dst_out), p(g.il_out), p(g.w_out), g.N, g.Kin, g.Kout, g.Bg, -1e20, 1.0, p(logZ), p(grad), None, p(ws), nbytes, None, None, None, 0,
         _native._stream()), 'band')
 torch.cuda.synchronize()
 wc0 = (g.N + 63) // 64 * 64
