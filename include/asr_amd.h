@@ -223,6 +223,16 @@ int asr_lattice_grouped_fwbw_f32(
     const int32_t *uniq, const int32_t *mem_g, const int32_t *mem_h, const float *term,
     float neg_inf, float *out_logZ, float *out_grad, float *out_logZ_bwd, void *workspace,
     int64_t workspace_bytes, void *stream);
+/* ... with accumulate != 0: out_grad += occupancies (rows past an utterance's end are left as they
+ * are) — the denominator of FSTDecoder.get_fst_loss (advanced_decoder.py:497-500) added onto the
+ * numerator's (negated) occupancies in the same buffer: d loss / d acts without a separate
+ * [T,B,C] addition (ABI v22). */
+int asr_lattice_grouped_fwbw_acc_f32(
+    const float *lp, int T, int B, int C, const int32_t *lens, int N, int G, int Wg, int Wh,
+    const int32_t *g_of, const int32_t *h_of, const int32_t *label, const int32_t *selfx,
+    const int32_t *uniq, const int32_t *mem_g, const int32_t *mem_h, const float *term,
+    float neg_inf, int accumulate, float *out_logZ, float *out_grad, float *out_logZ_bwd,
+    void *workspace, int64_t workspace_bytes, void *stream);
 
 int asr_lattice_grouped_forward_f32(
     const float *lp, int T, int B, int C, const int32_t *lens, int N, int G, int Wg, int Wh,

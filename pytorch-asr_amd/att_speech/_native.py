@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get(     # ASR_AMD_LIB: development override (kernel A/B b
     'ASR_AMD_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'libasr_amd.so'))
 
 ASR_OK, ASR_EINVAL, ASR_EUNSUPPORTED, ASR_ELAUNCH = 0, 1, 2, 3
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _lib = None
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs
@@ -78,6 +78,8 @@ _SIGNATURES = {
     'asr_lattice_grouped_workspace_bytes': (_i64, [_i, _i, _i, _i]),
     'asr_lattice_grouped_fwbw_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i] + [_vp] * 8 +
                                      [_f, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'asr_lattice_grouped_fwbw_acc_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i] + [_vp] * 8 +
+                                         [_f, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     'asr_lattice_grouped_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i] + [_vp] * 8 +
                                         [_f, _i, _vp, _vp, _vp, _i64, _vp]),
     'asr_lstm_workspace_bytes': (_i64, [_i, _i]),
@@ -677,20 +679,24 @@ class GroupedGraph(object):
                 _p(self.selfx), _p(self.uniq), _p(self.mem_g), _p(self.mem_h), _p(self.term))
 
 
-def grouped_fwbw(lp, lens, gg, neg_inf=-1e20, want_bwd_total=False):
-    """asr_lattice_grouped_fwbw_f32 -> (logZ [B], grad [T,B,C], logZ_bwd | None)."""
+def grouped_fwbw(lp, lens, gg, neg_inf=-1e20, want_bwd_total=False, add_to=None):
+    """asr_lattice_grouped_fwbw_f32 -> (logZ [B], grad [T,B,C], logZ_bwd | None); add_to: a
+    [T,B,C] f32 tensor the occupancies are ADDED to (asr_lattice_grouped_fwbw_acc_f32) and which
+    is returned as grad."""
     lp = _dev(lp, torch.float32, 'log_probs')
     lens = _dev(lens, torch.int32, 'act_lens')
     T, B, C = lp.shape
     L = lib()
     logZ = torch.empty(B, dtype=torch.float32, device=lp.device)
-    grad = torch.empty_like(lp)
+    if add_to is not None:
+        assert add_to.shape == lp.shape and add_to.is_contiguous() and add_to.dtype == torch.float32
+    grad = torch.empty_like(lp) if add_to is None else add_to
     zb = torch.empty(B, dtype=torch.float32, device=lp.device) if want_bwd_total else None
     nbytes = L.asr_lattice_grouped_workspace_bytes(T, B, gg.N, gg.G)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=lp.device)
-    check(L.asr_lattice_grouped_fwbw_f32(
-        _p(lp), T, B, C, _p(lens), *gg._args(), float(neg_inf), _p(logZ), _p(grad), _p(zb),
-        _p(ws), nbytes, _stream()), 'asr_lattice_grouped_fwbw_f32')
+    check(L.asr_lattice_grouped_fwbw_acc_f32(
+        _p(lp), T, B, C, _p(lens), *gg._args(), float(neg_inf), int(add_to is not None), _p(logZ),
+        _p(grad), _p(zb), _p(ws), nbytes, _stream()), 'asr_lattice_grouped_fwbw_acc_f32')
     return logZ, grad, zb
 
 

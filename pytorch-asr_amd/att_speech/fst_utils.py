@@ -209,6 +209,40 @@ class PathLogSumExp(torch.autograd.Function):
 path_logsumexp = PathLogSumExp.apply
 
 
+class NumeratorMinusDenominator(torch.autograd.Function):
+    """-logZ(numerator lattices) + logZ(shared decoding graph) per utterance — the globally
+    normalised loss of FSTDecoder.get_fst_loss (advanced_decoder.py:486-500:
+    `num - den` with num = -path_reduction(numerator), den = -path_reduction(denominator)) —
+    as ONE autograd node (an extension; two PathLogSumExp nodes give the same values): the
+    numerator kernel writes its negated occupancies, the denominator kernel adds its own onto
+    them in the same buffer (asr_lattice_grouped_fwbw_acc_f32), and the backward pass scales
+    that buffer in place (factor 1 in a training step: no pass at all).  Two nodes meant two
+    [T,B,C] tensors and autograd's addition of them: 7 GB of traffic per step for a bi-character
+    alphabet at 768 utterances."""
+
+    @staticmethod
+    def forward(ctx, log_probs, act_lens, numerator, grouped, neg_inf):
+        log_probs = log_probs.detach()
+        _assert_sorted(act_lens)
+        lens = _lens_on(act_lens, log_probs.device)
+        graph = _device_graph(numerator, log_probs.device)
+        # (the same constants as the two separate reductions: path_reduction evaluates training
+        # lattices with NEG_INF and the decoding graph with the caller's neg_inf)
+        zn, grads, _ = _native.lattice_fwbw(log_probs, lens, graph, NEG_INF, grad_sign=-1.0)
+        zd, grads, _ = _native.grouped_fwbw(log_probs, lens, grouped, neg_inf, add_to=grads)
+        ctx.grads = grads
+        ctx.mark_non_differentiable(zn, zd)
+        return zd - zn, zn, zd
+
+    @staticmethod
+    def backward(ctx, grad_output, _gn, _gd):
+        grads, ctx.grads = ctx.grads, None
+        if grads is None:
+            raise RuntimeError("NumeratorMinusDenominator: backward a second time (the occupancies "
+                               "are scaled in place and released after the first)")
+        return (_native.scale_rows_(grads, grad_output), None, None, None, None)
+
+
 class _PathViterbi(torch.autograd.Function):
     """max-plus alpha scan; d score / d log_probs is one-hot at the best path's
     input label of every active frame (what autograd gives the reference,

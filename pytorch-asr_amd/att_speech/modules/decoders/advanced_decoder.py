@@ -626,6 +626,16 @@ class FSTDecoder(_ProjectionDecoder):
             shifted, max_sum = _NormaliseShift.apply(logits, lens_dev)   # (:444-452) + (:479-484)
         else:
             shifted, max_sum = _SubRowMax.apply(logits, lens_dev)        # (:479-484)
+        if self.denominator_red in ('logsumexp', 'logsumexp_fwb') and \
+                self.numerator_red in ('logsumexp', 'logsumexp_fwb') and shifted.is_cuda and \
+                not self.verbose and os.environ.get('ASR_FUSED_NUMDEN', '1') != '0':
+            # both reductions in one autograd node: one gradient buffer, no [T,B,C] addition
+            den_graph = gg.get_decoding_matrices('cpu')
+            grouped = fst_utils._device_grouped(den_graph, shifted.device)
+            num_ok = isinstance(numerator, _native.Graph) or len(numerator) == 8
+            if grouped is not None and num_ok:
+                return fst_utils.NumeratorMinusDenominator.apply(
+                    shifted, encoded_lens, numerator, grouped, gg.nc_weight)[0]
         num = fst_utils.path_reduction(shifted, encoded_lens, numerator, red_kind=self.numerator_red,
                                        neg_inf=gg.nc_weight, negate=True)
         if self.denominator_red == 'none':

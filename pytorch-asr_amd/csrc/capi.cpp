@@ -1,7 +1,7 @@
 // Library-level C ABI helpers (version, error strings).
 #include "../../include/asr_amd.h"
 
-extern "C" int asr_abi_version(void) { return 21; }
+extern "C" int asr_abi_version(void) { return 22; }
 
 extern "C" const char *asr_strerror(int code) {
     switch (code) {

@@ -48,6 +48,7 @@ struct GroupedParams {
     int32_t *best_il;           // [T,B]
     int32_t *rarg;              // [T,B,G] arg-max member of every group (viterbi)
     uint8_t *bpself;            // [T,B,N] 1: best predecessor is the state itself
+    int accumulate;             // fwbw: grad += occupancies (rows past an utterance's end untouched)
 };
 
 constexpr int LPG = 16;         // lanes cooperating on one group sum
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(1024) void grouped_fwbw_kernel(GroupedParams p) {
     const size_t astride = (size_t)p.B * N;
     float *al_b = p.alphas + (size_t)b * N;
 
-    for (int t = len; t < p.T; ++t)                       // fst_utils.py:448
-        for (int c = tid; c < C; c += NT) grad_b[(size_t)t * tstride + c] = 0.f;
+    if (!p.accumulate)
+        for (int t = len; t < p.T; ++t)                   // fst_utils.py:448
+            for (int c = tid; c < C; c += NT) grad_b[(size_t)t * tstride + c] = 0.f;
     for (int n = tid; n < N; n += NT) {
         const float v = n == 0 ? 0.f : p.neg_inf;         // start state 0 (fst_utils.py:246)
         a0[n] = v;
@@ -161,7 +163,10 @@ __global__ __launch_bounds__(1024) void grouped_fwbw_kernel(GroupedParams p) {
         group_lse(p.mem_h, G, p.Wh, p.neg_inf, R, [&](int s) { return nxt[s]; });
         {   // stream the finished gradient row out while the group sums settle
             float *gout = grad_b + (size_t)t * tstride;
-            for (int c = tid; c < C; c += NT) gout[c] = row[c];
+            if (p.accumulate)
+                for (int c = tid; c < C; c += NT) gout[c] += row[c];
+            else
+                for (int c = tid; c < C; c += NT) gout[c] = row[c];
         }
         __syncthreads();
         for (int c = tid; c < C; c += NT) row[c] = 0.f;
@@ -245,8 +250,9 @@ __global__ __launch_bounds__(1024) void grouped_fwbw_fast_kernel(GroupedParams p
         for (int k = 0; k < SPT; ++k) o[k] = sv[k] ? lrow[slab[k]] : 0.f;
     };
 
-    for (int t = len; t < p.T; ++t)                       // fst_utils.py:448
-        for (int c = tid; c < C; c += NT) grad_b[(size_t)t * tstride + c] = 0.f;
+    if (!p.accumulate)
+        for (int t = len; t < p.T; ++t)                   // fst_utils.py:448
+            for (int c = tid; c < C; c += NT) grad_b[(size_t)t * tstride + c] = 0.f;
 #pragma unroll
     for (int k = 0; k < SPT; ++k)
         if (sv[k]) {
@@ -341,9 +347,16 @@ __global__ __launch_bounds__(1024) void grouped_fwbw_fast_kernel(GroupedParams p
         }
         {   // the finished gradient row leaves (and is cleared for the next frame)
             float *gout = grad_b + (size_t)t * tstride;
-            for (int c = tid; c < C; c += NT) {
-                gout[c] = row[c];
-                row[c] = 0.f;
+            if (p.accumulate) {
+                for (int c = tid; c < C; c += NT) {
+                    gout[c] += row[c];
+                    row[c] = 0.f;
+                }
+            } else {
+                for (int c = tid; c < C; c += NT) {
+                    gout[c] = row[c];
+                    row[c] = 0.f;
+                }
             }
         }
         __syncthreads();
@@ -505,12 +518,12 @@ extern "C" int64_t asr_lattice_grouped_workspace_bytes(int T, int B, int N, int 
     return (fw > vt ? fw : vt) + 256;
 }
 
-extern "C" int asr_lattice_grouped_fwbw_f32(
+extern "C" int asr_lattice_grouped_fwbw_acc_f32(
     const float *lp, int T, int B, int C, const int32_t *lens, int N, int G, int Wg, int Wh,
     const int32_t *g_of, const int32_t *h_of, const int32_t *label, const int32_t *selfx,
     const int32_t *uniq, const int32_t *mem_g, const int32_t *mem_h, const float *term,
-    float neg_inf, float *out_logZ, float *out_grad, float *out_logZ_bwd, void *workspace,
-    int64_t workspace_bytes, void *stream) {
+    float neg_inf, int accumulate, float *out_logZ, float *out_grad, float *out_logZ_bwd,
+    void *workspace, int64_t workspace_bytes, void *stream) {
     if (bad_common(lp, T, B, C, lens, N, G, Wg, Wh, g_of, h_of, label, selfx, uniq, mem_g,
                    mem_h, term))
         return ASR_EINVAL;
@@ -525,6 +538,7 @@ extern "C" int asr_lattice_grouped_fwbw_f32(
     p.mem_g = mem_g; p.mem_h = mem_h; p.term = term; p.neg_inf = neg_inf;
     p.logZ = out_logZ; p.grad = out_grad; p.logZ_bwd = out_logZ_bwd;
     p.alphas = (float *)workspace;
+    p.accumulate = accumulate ? 1 : 0;
     const size_t lds = (size_t)(2 * N + ((G + 3) & ~3) + ((C + 3) & ~3) + 64) * sizeof(float);
     if (lds > 160 * 1024) return ASR_EUNSUPPORTED;
     if (lds > 64 * 1024 &&
@@ -544,6 +558,17 @@ extern "C" int asr_lattice_grouped_fwbw_f32(
     }
     hipLaunchKernelGGL(grouped_fwbw_kernel, dim3(B), dim3(nt), lds, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+}
+
+extern "C" int asr_lattice_grouped_fwbw_f32(
+    const float *lp, int T, int B, int C, const int32_t *lens, int N, int G, int Wg, int Wh,
+    const int32_t *g_of, const int32_t *h_of, const int32_t *label, const int32_t *selfx,
+    const int32_t *uniq, const int32_t *mem_g, const int32_t *mem_h, const float *term,
+    float neg_inf, float *out_logZ, float *out_grad, float *out_logZ_bwd, void *workspace,
+    int64_t workspace_bytes, void *stream) {
+    return asr_lattice_grouped_fwbw_acc_f32(lp, T, B, C, lens, N, G, Wg, Wh, g_of, h_of, label, selfx, uniq,
+                                            mem_g, mem_h, term, neg_inf, 0, out_logZ, out_grad, out_logZ_bwd,
+                                            workspace, workspace_bytes, stream);
 }
 
 extern "C" int asr_lattice_grouped_forward_f32(

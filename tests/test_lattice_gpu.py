@@ -764,3 +764,37 @@ def test_band_kernel_from_labels_is_the_band_kernel_from_matrices(oracle_lib, mo
     want = oracle_lib.path_logsumexp(lp.numpy(), lens, mats)
     np.testing.assert_allclose(out['1'][0], want['logZ'], rtol=RTOL_LOSS, atol=1e-5)
     assert_posteriors(out['1'][1], want['grad'], lp.numpy(), lens, mats, oracle_lib)
+
+
+def test_numerator_minus_denominator_node_equals_two_reductions():
+    """fst_utils.NumeratorMinusDenominator (one gradient buffer: the numerator's negated
+    occupancies, the denominator's added onto them by asr_lattice_grouped_fwbw_acc_f32) against
+    -path_reduction(numerator) + path_reduction(decoding graph) as two autograd nodes: values
+    bit-equal, gradients to fp32 rounding of one addition, ragged lengths (rows past an
+    utterance's end stay zero) and non-unit incoming gradients."""
+    from att_speech import fst_utils as P
+    S, T, B, Lmax = 7, 50, 5, 9
+    rng = np.random.default_rng(123)
+    lens = np.array([50, 47, 40, 33, 21], np.int64)
+    llens = np.array([9, 4, 7, 1, 3], np.int64)
+    labs = rng.integers(1, S, size=(B, Lmax))
+    gg = P.CTCGraphGen(context_order=2, num_symbols=S)
+    num = gg.get_training_matrices_batch(labs, llens)
+    den = gg.get_decoding_matrices('cpu')
+    x = torch.from_numpy(rng.standard_normal((T, B, S * S)).astype(np.float32)).to(dev())
+    x = x - x.max(-1, keepdim=True)[0]
+    w = torch.tensor([1.0, 1.0, 2.0, 1.0, -0.5], device=dev())
+    tl = torch.from_numpy(lens)
+    grouped = P._device_grouped(den, x.device)
+    assert grouped is not None
+    for weights in (None, w):
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        la = P.path_reduction(a, tl, num, negate=True) + P.path_reduction(a, tl, den, neg_inf=gg.nc_weight)
+        lb = P.NumeratorMinusDenominator.apply(b, tl, num, grouped, gg.nc_weight)[0]
+        np.testing.assert_allclose(lb.detach().cpu().numpy(), la.detach().cpu().numpy(), rtol=1e-6, atol=1e-5)
+        (la.sum() if weights is None else (la * weights).sum()).backward()
+        (lb.sum() if weights is None else (lb * weights).sum()).backward()
+        np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
+        for i in range(B):
+            assert not b.grad[lens[i]:, i].any()
