@@ -430,7 +430,7 @@ def mono_lattice_kernel(B):
     return 'lattice_fwbw_band_kernel' if B <= _native._BAND_MAX_BATCH else 'lattice_fwbw_sl_kernel<3, 8, 1>'
 
 
-def pmc_traffic(order, B, T, kernel_tag=None):
+def pmc_traffic(order, B, T, kernel_tag=None, grid=None):
     """HBM bytes per lattice launch from the PMC passes committed under profiles/
     (r03_pmc_step_fetch_write.json: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
     runs of bench.py summarised by tools/pmc_summary.py; FETCH_SIZE counts half of a
@@ -446,8 +446,10 @@ def pmc_traffic(order, B, T, kernel_tag=None):
         if pmc.get('batch') != B:
             return None
         e = next(v for n, v in pmc['kernels'].items() if k in n)
-        if 'by_grid' in e:          # several problem sizes in the run: the largest launch is the measured one
-            e = e['by_grid'][max(e['by_grid'], key=int)]
+        if 'by_grid' in e:          # several problem sizes in the run: the launch with `grid` work items
+            # (the bi-char probe: 512 utterances x 512 threads), else the largest one
+            key = str(grid) if grid is not None and str(grid) in e['by_grid'] else max(e['by_grid'], key=int)
+            e = e['by_grid'][key]
         return (2 * e['fetch_KB'] + e['write_KB']) * 1024.0
     except (OSError, KeyError, ValueError, StopIteration, TypeError):
         return None
@@ -681,7 +683,7 @@ def main():
         if world == 1 and not a.no_extra:
             progress('bi-char numerator roofline launch')
             res['roofline_bichar'] = bichar_numerator_roofline(
-                dev, traffic=pmc_traffic(2, B, T, 'lattice_fwbw_sl_kernel<3, 8, 0>'))
+                dev, traffic=pmc_traffic(2, B, T, 'lattice_fwbw_sl_kernel<3, 8, 0>', grid=512 * 512))
             torch.cuda.empty_cache()
             progress('stage-2 decode rate')
             res['decode'] = tcn_decode_rate(dev)
