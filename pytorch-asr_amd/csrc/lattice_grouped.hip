@@ -187,8 +187,11 @@ __global__ __launch_bounds__(1024) void grouped_fwbw_kernel(GroupedParams p) {
 // description of its (<= SPT) states in registers, a lane of a group's 16-lane team keeps its
 // (<= 4) members of both lists in registers, and the log-probs / stored alphas of the NEXT
 // frame are loaded while the current one is computed.
-template <int SPT>
+// LG lanes share a group sum (64 / LG members per lane): 16 for 1024-thread workgroups, 8 for
+// the 512-thread ones that large batches get (four of them fit a CU, two of the others)
+template <int SPT, int LG = LPG>
 __global__ __launch_bounds__(1024) void grouped_fwbw_fast_kernel(GroupedParams p) {
+    constexpr int MPL = 64 / LG;
     extern __shared__ float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int N = p.N, G = p.G, C = p.C;
@@ -219,29 +222,29 @@ __global__ __launch_bounds__(1024) void grouped_fwbw_fast_kernel(GroupedParams p
         sterm[k] = p.term[nn];
     }
     // this lane's members of its group (both lists)
-    const bool glane = tid < G * LPG;
-    const int grp = tid / LPG, gl = tid % LPG;
-    int mg[4], mh[4];
+    const bool glane = tid < G * LG;
+    const int grp = tid / LG, gl = tid % LG;
+    int mg[MPL], mh[MPL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = gl + LPG * j;
+    for (int j = 0; j < MPL; ++j) {
+        const int idx = gl + LG * j;
         mg[j] = (glane && idx < p.Wg) ? p.mem_g[(size_t)grp * p.Wg + idx] : -1;
         mh[j] = (glane && idx < p.Wh) ? p.mem_h[(size_t)grp * p.Wh + idx] : -1;
     }
     auto group_lse_reg = [&](const float *val, const int *mem) -> float {
-        float v[4], m = p.neg_inf;
+        float v[MPL], m = p.neg_inf;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MPL; ++j) {
             v[j] = mem[j] >= 0 ? val[mem[j]] : p.neg_inf;
             m = fmaxf(m, v[j]);
         }
 #pragma unroll
-        for (int o = LPG / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, LPG));
+        for (int o = LG / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, LG));
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sum += mem[j] >= 0 ? __expf(v[j] - m) : 0.f;
+        for (int j = 0; j < MPL; ++j) sum += mem[j] >= 0 ? __expf(v[j] - m) : 0.f;
 #pragma unroll
-        for (int o = LPG / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, LPG);
+        for (int o = LG / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, LG);
         return sum > 0.f ? m + __logf(sum) : p.neg_inf;
     };
     auto lpload = [&](int t, float *o) {
@@ -549,6 +552,21 @@ extern "C" int asr_lattice_grouped_fwbw_acc_f32(
     if (nt < G * LPG) nt = round_up64(G * LPG);
     const int spt = (N + nt - 1) / nt;
     static const bool fast_on = !(getenv("ASR_GROUPED_FAST") && getenv("ASR_GROUPED_FAST")[0] == '0');
+    // 512-thread workgroups (five states per thread, eight lanes per group sum): four fit a CU
+    // instead of two, so 768 utterances are resident at once instead of in one and a half
+    // rounds (3.87 -> 3.06 ms), and at 256 utterances they are no slower (1.36 -> 1.32 ms).
+    // ASR_GROUPED_NT=1024: the 1024-thread arrangement (A/B switch)
+    static const char *nt_env = getenv("ASR_GROUPED_NT");
+    const bool small_wg = !(nt_env && atoi(nt_env) == 1024);
+    if (fast_on && small_wg && N > 512 && N <= 5 * 512 && Wg <= 64 && Wh <= 64 && G * 8 <= 512 &&
+        lds <= 64 * 1024) {
+        const int sp = (N + 511) / 512;
+        void (*kern)(GroupedParams) = sp <= 2 ? grouped_fwbw_fast_kernel<2, 8>
+                                      : sp == 3 ? grouped_fwbw_fast_kernel<3, 8>
+                                      : sp == 4 ? grouped_fwbw_fast_kernel<4, 8> : grouped_fwbw_fast_kernel<5, 8>;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds, (hipStream_t)stream, p);
+        return hipGetLastError() == hipSuccess ? ASR_OK : ASR_ELAUNCH;
+    }
     if (fast_on && Wg <= 4 * LPG && Wh <= 4 * LPG && spt <= 4 && nt <= 1024 && lds <= 64 * 1024) {
         void (*kern)(GroupedParams) = spt <= 1 ? grouped_fwbw_fast_kernel<1>
                                       : spt == 2 ? grouped_fwbw_fast_kernel<2>
